@@ -1,0 +1,363 @@
+"""
+cpu_ray_tracer_amd — ctypes binding of libcrt_amd.so (the MI355X path-tracing back end).
+
+This module is plumbing only: every call goes straight to the C ABI declared in include/crt_abi.h and
+include/crt_host.h.  There is no Python or CPU implementation of the path behind it — if the shared library is
+missing, or no HIP device is visible, the calls raise.
+
+The directory is named `cpu-ray-tracer_amd` (not an importable identifier); load it with
+    importlib.util.spec_from_file_location("cpu_ray_tracer_amd", ".../cpu-ray-tracer_amd/__init__.py")
+as __graft_entry__.py, bench.py and tests/conftest.py do.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libcrt_amd.so")
+
+SCENE_FILE, SCENE_TLAS = 0, 1
+
+
+class CrtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("crt error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("depthLimit", C.c_int32), ("device", C.c_int32),
+                ("tileFirst", C.c_int32), ("tileStride", C.c_int32), ("tileCount", C.c_int32),
+                ("maxFramesPerLaunch", C.c_int32), ("collectStats", C.c_int32)]
+
+
+class CountersS(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "primary", "interior_iters", "leaf_iters", "tri_tests", "tlas_iters", "blas_visits", "mesh_hits")]
+
+
+class TimingS(C.Structure):
+    _fields_ = [("render_kernel_ms", C.c_float), ("resolve_kernel_ms", C.c_float), ("render_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+TRI_DTYPE = np.dtype([("vertex0", "<f4", 3), ("vertex1", "<f4", 3), ("vertex2", "<f4", 3),
+                      ("normal0", "<f4", 3), ("normal1", "<f4", 3), ("normal2", "<f4", 3),
+                      ("uv0", "<f4", 2), ("uv1", "<f4", 2), ("uv2", "<f4", 2), ("centroid", "<f4", 3), ("objIdx", "<i4")])
+NODE_DTYPE = np.dtype([("aabbMin", "<f4", 3), ("aabbMax", "<f4", 3), ("leftFirst", "<u4"), ("triCount", "<u4")])
+TLAS_DTYPE = np.dtype([("aabbMin", "<f4", 3), ("leftRight", "<u4"), ("aabbMax", "<f4", 3), ("BLAS", "<u4")])
+RAY_DTYPE = np.dtype([("O", "<f4", 3), ("D", "<f4", 3), ("inside", "<i4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("objIdx", "<i4"), ("triIdx", "<i4"), ("traversed", "<i4"), ("tested", "<i4")])
+
+# every symbol include/crt_abi.h and include/crt_host.h declare (tests check the library exports all of them)
+ABI_SYMBOLS = ["crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
+               "crt_render", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
+               "crt_reset_counters", "crt_get_timing", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
+HOST_SYMBOLS = ["crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
+                "crt_host_scene_triangle_count", "crt_host_scene_bvh_count", "crt_host_scene_bvh_info", "crt_host_scene_bvh_copy",
+                "crt_host_scene_blas_transform", "crt_host_scene_tlas_copy", "crt_host_camera_state", "crt_host_renderer_create",
+                "crt_host_renderer_destroy", "crt_host_renderer_init", "crt_host_renderer_set_camera", "crt_host_renderer_set_passes",
+                "crt_host_renderer_clear", "crt_host_renderer_tick", "crt_host_renderer_render", "crt_host_renderer_spp",
+                "crt_host_renderer_energy", "crt_host_renderer_accumulator", "crt_host_renderer_screen", "crt_host_renderer_ctx",
+                "crt_host_obj_load", "crt_host_image_load", "crt_host_free"]
+
+
+def build(force=False):
+    """Compile libcrt_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(HERE, "Makefile")]
+    for root, _, files in os.walk(os.path.join(HERE, "csrc")):
+        srcs += [os.path.join(root, f) for f in files]
+    srcs += [os.path.join(REPO, "include", f) for f in ("crt_abi.h", "crt_host.h")]
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", HERE] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (there is no fallback path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.crt_last_error.restype = C.c_char_p
+        L.crt_last_error.argtypes = [C.c_void_p]
+        L.crt_host_last_error.restype = C.c_char_p
+        L.crt_host_renderer_energy.restype = C.c_float
+        L.crt_host_renderer_accumulator.restype = C.POINTER(C.c_float)
+        L.crt_host_renderer_screen.restype = C.POINTER(C.c_uint32)
+        L.crt_host_renderer_ctx.restype = C.c_void_p
+        L.crt_destroy.argtypes = [C.c_void_p]
+        L.crt_host_scene_free.argtypes = [C.c_void_p]
+        L.crt_host_renderer_destroy.argtypes = [C.c_void_p]
+        L.crt_host_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def device_count():
+    return int(lib().crt_device_count())
+
+
+class Context:
+    """crt_ctx: one device, one image (or a strided subset of its 16x16 tiles)."""
+
+    def __init__(self, width, height, depth_limit=5, device=0, tile_first=0, tile_stride=1, tile_count=-1,
+                 max_frames_per_launch=0, collect_stats=False):
+        self.L = lib()
+        cfg = Config(width, height, depth_limit, device, tile_first, tile_stride, tile_count, max_frames_per_launch, int(collect_stats))
+        h = C.c_void_p()
+        rc = self.L.crt_create(C.byref(h), C.byref(cfg))
+        if rc != 0:
+            raise CrtError(rc, self.L.crt_last_error(None).decode())
+        self.h = h
+        self.W, self.H = width, height
+        self._owned = True
+
+    @classmethod
+    def borrow(cls, handle, width, height):
+        o = cls.__new__(cls)
+        o.L = lib()
+        o.h = C.c_void_p(handle)
+        o.W, o.H = width, height
+        o._owned = False
+        return o
+
+    def close(self):
+        if getattr(self, "h", None) and self._owned:
+            self.L.crt_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise CrtError(rc, self.L.crt_last_error(self.h).decode())
+
+    def set_camera(self, cam_pos, top_left, top_right, bottom_left):
+        self._ck(self.L.crt_set_camera(self.h, _f3(cam_pos), _f3(top_left), _f3(top_right), _f3(bottom_left)))
+
+    def set_camera_state(self, position, target):
+        a = [(C.c_float * 3)() for _ in range(4)]
+        rc = self.L.crt_host_camera_state(self.W, self.H, _f3(position), _f3(target), *a)
+        if rc != 0:
+            raise CrtError(rc, self.L.crt_host_last_error().decode())
+        self._ck(self.L.crt_set_camera(self.h, *a))
+
+    def render(self, spp_first, frames, passes=1):
+        self._ck(self.L.crt_render(self.h, C.c_uint32(spp_first), C.c_uint32(frames), C.c_uint32(passes)))
+
+    def sync(self):
+        self._ck(self.L.crt_sync(self.h))
+
+    def clear(self):
+        self._ck(self.L.crt_clear(self.h))
+
+    def accumulator(self):
+        a = np.empty((self.H, self.W, 4), np.float32)
+        self._ck(self.L.crt_read_accumulator(self.h, _p(a)))
+        return a
+
+    def resolve_screen(self, scale):
+        px = np.empty((self.H, self.W), np.uint32)
+        e = C.c_float()
+        self._ck(self.L.crt_resolve_screen(self.h, C.c_float(scale), _p(px), C.byref(e)))
+        return px, e.value
+
+    def find_nearest(self, O, D, inside=None):
+        O = np.asarray(O, np.float32).reshape(-1, 3)
+        D = np.asarray(D, np.float32).reshape(-1, 3)
+        rays = np.zeros(O.shape[0], RAY_DTYPE)
+        rays["O"], rays["D"] = O, D
+        if inside is not None:
+            rays["inside"] = inside
+        hits = np.zeros(O.shape[0], HIT_DTYPE)
+        self._ck(self.L.crt_find_nearest(self.h, _p(rays), _p(hits), C.c_size_t(O.shape[0])))
+        return hits
+
+    def counters(self):
+        c = CountersS()
+        self._ck(self.L.crt_get_counters(self.h, C.byref(c)))
+        return {n: int(getattr(c, n)) for n, _ in c._fields_}
+
+    def reset_counters(self):
+        self._ck(self.L.crt_reset_counters(self.h))
+
+    def timing(self):
+        t = TimingS()
+        self._ck(self.L.crt_get_timing(self.h, C.byref(t)))
+        return dict(render_kernel_ms=t.render_kernel_ms, resolve_kernel_ms=t.resolve_kernel_ms, render_launches=t.render_launches)
+
+    def bind_accumulator(self, device_ptr):
+        self._ck(self.L.crt_bind_accumulator(self.h, C.c_void_p(device_ptr)))
+
+    def accumulator_device_ptr(self):
+        p = C.c_void_p()
+        self._ck(self.L.crt_accumulator_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+
+class HostScene:
+    """FileScene / TLASFileScene built on the CPU by the C++ host front (XML + OBJ + textures + SAH-BVH / TLAS)."""
+
+    def __init__(self, xml_path, kind, base_dir=None):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.crt_host_scene_load(xml_path.encode(), int(kind), (base_dir or "").encode(), C.byref(h))
+        if rc != 0:
+            raise CrtError(rc, self.L.crt_host_last_error().decode())
+        self.h = h
+        self.kind = int(kind)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.crt_host_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise CrtError(rc, self.L.crt_host_last_error().decode())
+
+    def upload(self, ctx):
+        self._ck(self.L.crt_host_scene_upload(self.h, ctx.h))
+
+    def triangle_count(self):
+        return self.L.crt_host_scene_triangle_count(self.h)
+
+    def bvh_count(self):
+        return self.L.crt_host_scene_bvh_count(self.h)
+
+    def bvh(self, i=0):
+        nu, tc, md = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self.L.crt_host_scene_bvh_info(self.h, i, C.byref(nu), C.byref(tc), C.byref(md)))
+        nodes = np.zeros(nu.value, NODE_DTYPE)
+        idx = np.zeros(tc.value, np.uint32)
+        tris = np.zeros(tc.value, TRI_DTYPE)
+        self._ck(self.L.crt_host_scene_bvh_copy(self.h, i, _p(nodes), _p(idx), _p(tris)))
+        return dict(nodes=nodes, triIndices=idx, tris=tris, nodesUsed=nu.value, maxDepth=md.value)
+
+    def blas_transform(self, i):
+        T, invT, lo, hi = np.zeros(16, np.float32), np.zeros(16, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._ck(self.L.crt_host_scene_blas_transform(self.h, i, _p(T), _p(invT), _p(lo), _p(hi)))
+        return T, invT, lo, hi
+
+    def tlas(self):
+        nodes = np.zeros(2 * self.bvh_count(), TLAS_DTYPE)
+        nu = C.c_uint32()
+        self._ck(self.L.crt_host_scene_tlas_copy(self.h, _p(nodes), C.byref(nu)))
+        return nodes, nu.value
+
+
+class HostRenderer:
+    """Renderer facade: Init / Tick / ClearAccumulator with the reference's public members."""
+
+    def __init__(self, scene, width, height, device=0):
+        self.L = lib()
+        self.scene = scene
+        h = C.c_void_p()
+        rc = self.L.crt_host_renderer_create(scene.h, width, height, device, C.byref(h))
+        if rc != 0:
+            raise CrtError(rc, self.L.crt_host_last_error().decode())
+        self.h = h
+        self.W, self.H = width, height
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.crt_host_renderer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise CrtError(rc, self.L.crt_host_last_error().decode())
+
+    def init(self):
+        self._ck(self.L.crt_host_renderer_init(self.h))
+
+    def set_camera(self, position, target):
+        self._ck(self.L.crt_host_renderer_set_camera(self.h, _f3(position), _f3(target)))
+
+    def set_passes(self, passes):
+        self._ck(self.L.crt_host_renderer_set_passes(self.h, passes))
+
+    def clear(self):
+        self._ck(self.L.crt_host_renderer_clear(self.h))
+
+    def tick(self, dt=0.0):
+        self._ck(self.L.crt_host_renderer_tick(self.h, C.c_float(dt)))
+
+    def render(self, frames):
+        self._ck(self.L.crt_host_renderer_render(self.h, frames))
+
+    @property
+    def spp(self):
+        return self.L.crt_host_renderer_spp(self.h)
+
+    @property
+    def energy(self):
+        return float(self.L.crt_host_renderer_energy(self.h))
+
+    def accumulator(self):
+        p = self.L.crt_host_renderer_accumulator(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.H, self.W, 4)).copy()
+
+    def screen(self):
+        p = self.L.crt_host_renderer_screen(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.H, self.W)).copy()
+
+    def context(self):
+        return Context.borrow(self.L.crt_host_renderer_ctx(self.h), self.W, self.H)
+
+
+def load_obj(path):
+    L = lib()
+    n = C.c_uint32()
+    pp, pn, pu = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+    rc = L.crt_host_obj_load(path.encode(), C.byref(n), C.byref(pp), C.byref(pn), C.byref(pu))
+    if rc != 0:
+        raise CrtError(rc, L.crt_host_last_error().decode())
+    pos = np.ctypeslib.as_array(pp, shape=(n.value, 3)).copy()
+    nrm = np.ctypeslib.as_array(pn, shape=(n.value, 3)).copy()
+    uv = np.ctypeslib.as_array(pu, shape=(n.value, 2)).copy()
+    for q in (pp, pn, pu):
+        L.crt_host_free(C.cast(q, C.c_void_p))
+    return pos, nrm, uv
+
+
+def load_image(path):
+    L = lib()
+    w, h = C.c_int(), C.c_int()
+    px = C.POINTER(C.c_uint32)()
+    rc = L.crt_host_image_load(path.encode(), C.byref(w), C.byref(h), C.byref(px))
+    if rc != 0:
+        raise CrtError(rc, L.crt_host_last_error().decode())
+    a = np.ctypeslib.as_array(px, shape=(h.value, w.value)).copy()
+    L.crt_host_free(C.cast(px, C.c_void_p))
+    return a

@@ -1,0 +1,519 @@
+// abi.cpp — implementation of include/crt_abi.h: context, scene flattening + upload, launches, read-back.
+// Host-only logic; the kernels live in device/kernels.hip.  There is NO CPU rendering path in this library:
+// without a HIP device crt_create fails with CRT_ERR_NO_DEVICE.
+#include "../../include/crt_abi.h"
+#include "device/layout.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_resolve(const void*, uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float, hipStream_t);
+
+static_assert(sizeof(crt_bvh_node) == 32 && sizeof(crt_tri) == 112 && sizeof(crt_tlas_node) == 32, "reference layouts");
+static_assert(sizeof(crt::NodePair) == 64 && sizeof(crt::LeafTri) == 48 && sizeof(crt::ShadeTri) == 64 && sizeof(crt::TlasNode) == 32 &&
+              sizeof(crt::Instance) == 128 && sizeof(crt::Material) == 32, "device layouts");
+static_assert(sizeof(crt_counters) == sizeof(crt::Counters), "counter layout");
+
+namespace {
+
+thread_local std::string g_createError;
+
+struct EventPair { hipEvent_t a, b; };
+
+} // namespace
+
+struct crt_ctx {
+    crt_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    int tilesX = 0, tilesY = 0;
+    uint32_t tileFirst = 0, tileStride = 1, tileCount = 0;
+    // device memory
+    void* dAccOwned = nullptr; void* dAcc = nullptr;
+    void* dSlab = nullptr; size_t slabBytes = 0;
+    crt::Scene hScene{}; crt::Scene* dScene = nullptr;
+    crt::Counters* dCounters = nullptr;
+    uint32_t* dPixels = nullptr; float* dTileSums = nullptr;
+    std::vector<void*> sceneAllocs;
+    bool haveScene = false;
+    uint32_t ldsBytes = 0;
+    // timing of the last crt_render
+    std::vector<EventPair> evPool; size_t evUsedRender = 0, evUsedAcc = 0;
+    std::vector<EventPair> evRender, evAcc;
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[1024];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+        err = buf; return code;
+    }
+    int hip(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return 0;
+        return fail(CRT_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+    }
+    void freeScene()
+    {
+        for (void* p : sceneAllocs) (void)hipFree(p);
+        sceneAllocs.clear(); haveScene = false;
+    }
+};
+
+#define HIPCK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (ctx)->hip(e_, #call); } while (0)
+
+namespace {
+
+template <class T>
+int upload(crt_ctx* c, const std::vector<T>& v, const T** out)
+{
+    *out = nullptr;
+    if (v.empty()) return 0;
+    void* d = nullptr;
+    HIPCK(c, hipMalloc(&d, v.size() * sizeof(T)));
+    c->sceneAllocs.push_back(d);
+    HIPCK(c, hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));   // v is a temporary of the caller
+    *out = reinterpret_cast<const T*>(d);
+    return 0;
+}
+
+// height of the tree below node 0 in pushes: the ordered traversal pushes at most one sibling per interior level
+int bvh_height(crt_ctx* c, const crt_bvh& b, uint32_t* heightOut)
+{
+    std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 0u});
+    uint32_t h = 0; size_t visited = 0;
+    while (!st.empty()) {
+        auto [n, d] = st.back(); st.pop_back();
+        if (++visited > (size_t)b.nodesUsed) return c->fail(CRT_ERR_INVALID, "BVH node graph is not a tree");
+        const crt_bvh_node& nd = b.nodes[n];
+        if (nd.triCount > 0) { if (d > h) h = d; continue; }
+        if (nd.leftFirst == 0 || nd.leftFirst + 1 >= b.nodesUsed) return c->fail(CRT_ERR_INVALID, "BVH child index out of range (node %u)", n);
+        st.push_back({nd.leftFirst, d + 1}); st.push_back({nd.leftFirst + 1, d + 1});
+    }
+    *heightOut = h;
+    return 0;
+}
+
+int node_ref(crt_ctx* c, const crt_bvh& b, uint32_t n, uint32_t* ref)
+{
+    const crt_bvh_node& nd = b.nodes[n];
+    if (nd.triCount > 0) {
+        if (nd.triCount > crt::kMaxLeafTris)
+            return c->fail(CRT_ERR_UNSUPPORTED, "leaf with %u triangles: this build packs at most %u per leaf", nd.triCount, crt::kMaxLeafTris);
+        if ((uint64_t)nd.leftFirst + nd.triCount > b.triCount) return c->fail(CRT_ERR_INVALID, "leaf range out of bounds (node %u)", n);
+        *ref = (nd.triCount << 24) | nd.leftFirst;
+    } else {
+        if ((nd.leftFirst & 1u) == 0) return c->fail(CRT_ERR_INVALID, "interior node %u: children must be allocated pairwise starting at an odd index", n);
+        *ref = crt::kInteriorFlag | ((nd.leftFirst - 1u) >> 1);
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int crt_abi_version(void) { return CRT_ABI_VERSION; }
+
+int crt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* crt_last_error(crt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+
+int crt_create(crt_ctx** out, const crt_config* cfg)
+{
+    if (!out || !cfg) { g_createError = "crt_create: null argument"; return CRT_ERR_INVALID; }
+    *out = nullptr;
+    if (cfg->width < 16 || cfg->height < 16) { g_createError = "crt_create: width and height must be at least one 16x16 tile"; return CRT_ERR_INVALID; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        g_createError = "crt_create: no HIP device visible (this library has no CPU path)";
+        return CRT_ERR_NO_DEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_createError = "crt_create: device ordinal out of range"; return CRT_ERR_INVALID; }
+    crt_ctx* c = new crt_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.depthLimit < 0) c->cfg.depthLimit = 5;
+    if (c->cfg.depthLimit > 5) { g_createError = "crt_create: depthLimit > 5 unsupported (throughput stack holds 5 factors; reference default is 5)"; delete c; return CRT_ERR_UNSUPPORTED; }
+    if (c->cfg.maxFramesPerLaunch <= 0 || c->cfg.maxFramesPerLaunch > 64) c->cfg.maxFramesPerLaunch = 64;
+    c->tilesX = cfg->width / 16; c->tilesY = cfg->height / 16;      // truncating, as renderer.cpp:151
+    const int tiles = c->tilesX * c->tilesY;
+    int first = cfg->tileFirst, stride = cfg->tileStride <= 0 ? 1 : cfg->tileStride, count = cfg->tileCount;
+    if (count < 0) { first = 0; stride = 1; count = tiles; }
+    if (first < 0 || (count > 0 && (long long)first + (long long)(count - 1) * stride >= tiles)) {
+        g_createError = "crt_create: tile range exceeds the image"; delete c; return CRT_ERR_INVALID;
+    }
+    c->tileFirst = (uint32_t)first; c->tileStride = (uint32_t)stride; c->tileCount = (uint32_t)count;
+
+    auto bail = [&](hipError_t he, const char* what) {
+        g_createError = std::string("crt_create: ") + what + ": " + hipGetErrorString(he);
+        crt_destroy(c); return CRT_ERR_DEVICE;
+    };
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    const size_t px = (size_t)cfg->width * cfg->height;
+    if ((e = hipMalloc(&c->dAccOwned, px * 16)) != hipSuccess) return bail(e, "hipMalloc(accumulator)");
+    c->dAcc = c->dAccOwned;
+    if ((e = hipMemsetAsync(c->dAcc, 0, px * 16, c->stream)) != hipSuccess) return bail(e, "hipMemset(accumulator)");
+    if ((e = hipMalloc((void**)&c->dPixels, px * 4)) != hipSuccess) return bail(e, "hipMalloc(pixels)");
+    if ((e = hipMemsetAsync(c->dPixels, 0, px * 4, c->stream)) != hipSuccess) return bail(e, "hipMemset(pixels)");
+    if ((e = hipMalloc((void**)&c->dTileSums, (size_t)tiles * 4)) != hipSuccess) return bail(e, "hipMalloc(tileSums)");
+    if ((e = hipMemsetAsync(c->dTileSums, 0, (size_t)tiles * 4, c->stream)) != hipSuccess) return bail(e, "hipMemset(tileSums)");
+    if ((e = hipMalloc((void**)&c->dCounters, sizeof(crt::Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemsetAsync(c->dCounters, 0, sizeof(crt::Counters), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
+    if ((e = hipMalloc((void**)&c->dScene, sizeof(crt::Scene))) != hipSuccess) return bail(e, "hipMalloc(scene)");
+    // Camera() defaults, template/camera.h:14-22
+    memset(&c->hScene, 0, sizeof(c->hScene));
+    const float aspect = (float)cfg->width / (float)cfg->height;
+    crt::Scene& s = c->hScene;
+    s.camPos[0] = 0; s.camPos[1] = 0; s.camPos[2] = -2;
+    s.topLeft[0] = -aspect; s.topLeft[1] = 1; s.topLeft[2] = 0;
+    s.topRight[0] = aspect; s.topRight[1] = 1; s.topRight[2] = 0;
+    s.bottomLeft[0] = -aspect; s.bottomLeft[1] = -1; s.bottomLeft[2] = 0;
+    s.W = cfg->width; s.H = cfg->height; s.invW = 1.0f / cfg->width; s.invH = 1.0f / cfg->height;
+    s.depthLimit = c->cfg.depthLimit;
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    *out = c;
+    return CRT_OK;
+}
+
+void crt_destroy(crt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->freeScene();
+    for (auto& ev : c->evPool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    if (c->dAccOwned) (void)hipFree(c->dAccOwned);
+    if (c->dSlab) (void)hipFree(c->dSlab);
+    if (c->dPixels) (void)hipFree(c->dPixels);
+    if (c->dTileSums) (void)hipFree(c->dTileSums);
+    if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->dScene) (void)hipFree(c->dScene);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
+{
+    if (!c || !sd) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (sd->kind != CRT_SCENE_FILE && sd->kind != CRT_SCENE_TLAS) return c->fail(CRT_ERR_INVALID, "unknown scene kind %d", sd->kind);
+    if (!sd->bvhs || sd->bvhCount == 0) return c->fail(CRT_ERR_INVALID, "scene has no acceleration structure");
+    if (sd->kind == CRT_SCENE_FILE && sd->bvhCount != 1) return c->fail(CRT_ERR_INVALID, "CRT_SCENE_FILE takes exactly one BVH (FileScene::acc)");
+    if (sd->kind == CRT_SCENE_TLAS && (sd->bvhCount > 256 || !sd->tlasNodes || sd->tlasNodeCount < 2 * sd->bvhCount))
+        return c->fail(CRT_ERR_INVALID, "TLAS scene needs <= 256 BLAS (tlas_bvh.cpp:21) and 2*blasCount TLAS nodes");
+    if (sd->textureCount == 0 || !sd->textures) return c->fail(CRT_ERR_INVALID, "floor and skydome textures are required");
+    if (sd->floorTexture < 0 || sd->floorTexture >= (int)sd->textureCount || sd->skyTexture < 0 || sd->skyTexture >= (int)sd->textureCount)
+        return c->fail(CRT_ERR_INVALID, "floor/sky texture index out of range");
+    for (uint32_t i = 0; i < sd->textureCount; i++)
+        if (!sd->textures[i].pixels || sd->textures[i].width <= 0 || sd->textures[i].height <= 0) return c->fail(CRT_ERR_INVALID, "texture %u is empty", i);
+    for (uint32_t i = 0; i < sd->materialCount; i++)
+        if (sd->materials[i].texture >= (int)sd->textureCount) return c->fail(CRT_ERR_INVALID, "material %u: texture index out of range", i);
+
+    c->freeScene();
+    std::vector<crt::NodePair> pairs; std::vector<crt::LeafTri> leaf; std::vector<crt::ShadeTri> shade; std::vector<crt::Instance> inst;
+    uint32_t maxHeight = 0, rootRef0 = 0;
+    for (uint32_t bi = 0; bi < sd->bvhCount; bi++) {
+        const crt_bvh& b = sd->bvhs[bi];
+        if (!b.nodes || !b.triangles || !b.triangleIndices || b.nodesUsed == 0 || b.triCount == 0) return c->fail(CRT_ERR_INVALID, "BVH %u is empty", bi);
+        if ((b.nodesUsed & 1u) == 0) return c->fail(CRT_ERR_INVALID, "BVH %u: nodesUsed must be odd (root + child pairs)", bi);
+        if (sd->kind == CRT_SCENE_TLAS && (b.matIdx < 0 || b.matIdx >= (int)sd->materialCount)) return c->fail(CRT_ERR_INVALID, "BLAS %u: matIdx out of range", bi);
+        uint32_t h = 0; int r = bvh_height(c, b, &h); if (r) return r;
+        if (h > maxHeight) maxHeight = h;
+        const uint32_t pairBase = (uint32_t)pairs.size(), leafBase = (uint32_t)leaf.size(), shadeBase = (uint32_t)shade.size();
+        if ((uint64_t)leafBase + b.triCount > crt::kMaxLeafSlots && sd->kind == CRT_SCENE_FILE) return c->fail(CRT_ERR_UNSUPPORTED, "more than 2^24 triangles in one BVH");
+        if (b.triCount > crt::kMaxLeafSlots) return c->fail(CRT_ERR_UNSUPPORTED, "more than 2^24 triangles in one BVH");
+        // node pairs
+        for (uint32_t n = 1; n + 1 < b.nodesUsed; n += 2) {
+            crt::NodePair p; memset(&p, 0, sizeof(p));
+            for (int k = 0; k < 2; k++) {
+                const crt_bvh_node& nd = b.nodes[n + k];
+                memcpy(p.c[k].lo, nd.aabbMin, 12); memcpy(p.c[k].hi, nd.aabbMax, 12);
+                r = node_ref(c, b, n + k, &p.c[k].ref); if (r) return r;
+            }
+            pairs.push_back(p);
+        }
+        uint32_t rootRef = 0; r = node_ref(c, b, 0, &rootRef); if (r) return r;
+        // triangles in leaf order + shading records in triIdx order
+        for (uint32_t j = 0; j < b.triCount; j++) {
+            const uint32_t ti = b.triangleIndices[j];
+            if (ti >= b.triCount) return c->fail(CRT_ERR_INVALID, "BVH %u: triangleIndices[%u] out of range", bi, j);
+            const crt_tri& t = b.triangles[ti];
+            crt::LeafTri lt; memset(&lt, 0, sizeof(lt));
+            for (int k = 0; k < 3; k++) { lt.v0[k] = t.vertex0[k]; lt.e1[k] = t.vertex1[k] - t.vertex0[k]; lt.e2[k] = t.vertex2[k] - t.vertex0[k]; }
+            lt.triIdx = ti;
+            lt.objIdx = (sd->kind == CRT_SCENE_TLAS) ? b.objIdx : t.objIdx;
+            if (sd->kind == CRT_SCENE_FILE && (t.objIdx < 2 || (uint32_t)(t.objIdx - 2) >= sd->objCount))
+                return c->fail(CRT_ERR_INVALID, "triangle %u: objIdx %d has no entry in objMatIdx", ti, t.objIdx);
+            leaf.push_back(lt);
+        }
+        for (uint32_t ti = 0; ti < b.triCount; ti++) {
+            const crt_tri& t = b.triangles[ti];
+            crt::ShadeTri s; memset(&s, 0, sizeof(s));
+            memcpy(s.n0, t.normal0, 12); memcpy(s.n1, t.normal1, 12); memcpy(s.n2, t.normal2, 12);
+            memcpy(s.uv0, t.uv0, 8); memcpy(s.uv1, t.uv1, 8); memcpy(s.uv2, t.uv2, 8);
+            s.objIdx = t.objIdx;
+            shade.push_back(s);
+        }
+        if (sd->kind == CRT_SCENE_TLAS) {
+            if (b.objIdx != (int)bi + 2) return c->fail(CRT_ERR_INVALID, "BLAS %u: objIdx must be %u (TLASFileScene numbers objects from 2, tlas_file_scene.cpp:13,51-53)", bi, bi + 2);
+            crt::Instance in; memset(&in, 0, sizeof(in));
+            memcpy(in.invT, b.invT, 48); memcpy(in.T, b.T, 48);
+            in.pairBase = pairBase; in.leafBase = leafBase; in.shadeBase = shadeBase; in.matIdx = b.matIdx; in.rootRef = rootRef; in.objIdx = b.objIdx;
+            inst.push_back(in);
+        } else {
+            rootRef0 = rootRef;
+        }
+    }
+    // LeafTri refs inside a BLAS are local to its leafBase (the kernel offsets the pointer); for the single BVH leafBase is 0.
+    std::vector<crt::TlasNode> tlas; uint32_t tlasHeight = 0, tlasRoot = 0;
+    if (sd->kind == CRT_SCENE_TLAS) {
+        tlas.resize(sd->tlasNodeCount);
+        memcpy(tlas.data(), sd->tlasNodes, sizeof(crt::TlasNode) * sd->tlasNodeCount);
+        // validate + height
+        std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 0u}); size_t visited = 0;
+        while (!st.empty()) {
+            auto [n, d] = st.back(); st.pop_back();
+            if (++visited > (size_t)sd->tlasNodeCount) return c->fail(CRT_ERR_INVALID, "TLAS node graph is not a tree");
+            const crt_tlas_node& nd = sd->tlasNodes[n];
+            if (nd.leftRight == 0) { if (nd.BLAS >= sd->bvhCount) return c->fail(CRT_ERR_INVALID, "TLAS leaf references BLAS %u", nd.BLAS); if (d > tlasHeight) tlasHeight = d; continue; }
+            const uint32_t l = nd.leftRight & 0xffffu, r = nd.leftRight >> 16;
+            if (l >= sd->tlasNodeCount || r >= sd->tlasNodeCount || (nd.leftRight & crt::kInteriorFlag)) return c->fail(CRT_ERR_INVALID, "TLAS child index out of range");
+            st.push_back({l, d + 1}); st.push_back({r, d + 1});
+        }
+        const crt_tlas_node& root = sd->tlasNodes[0];
+        tlasRoot = root.leftRight ? root.leftRight : (crt::kInteriorFlag | root.BLAS);
+    }
+    // materials: [0] light, [1] floor, then the scene's (file_scene.cpp:10-12, 30-38)
+    std::vector<crt::Material> mats(2 + sd->materialCount);
+    memset(mats.data(), 0, mats.size() * sizeof(crt::Material));
+    mats[0].isLight = 1; mats[0].tex = -1;
+    mats[1].tex = sd->floorTexture;
+    for (uint32_t i = 0; i < sd->materialCount; i++) {
+        crt::Material& m = mats[2 + i];
+        m.reflectivity = sd->materials[i].reflectivity; m.refractivity = sd->materials[i].refractivity;
+        memcpy(m.absorption, sd->materials[i].absorption, 12); m.tex = sd->materials[i].texture < 0 ? -1 : sd->materials[i].texture;
+    }
+    std::vector<int32_t> objMat;
+    if (sd->kind == CRT_SCENE_FILE) {
+        if (!sd->objMatIdx || sd->objCount == 0) return c->fail(CRT_ERR_INVALID, "CRT_SCENE_FILE needs objMatIdx");
+        objMat.assign(sd->objMatIdx, sd->objMatIdx + sd->objCount);
+        for (int32_t m : objMat) if (m < 0 || m >= (int)sd->materialCount) return c->fail(CRT_ERR_INVALID, "objMatIdx entry out of range");
+    }
+    // texel pool
+    std::vector<crt::TexDesc> tex(sd->textureCount); size_t texels = 0;
+    for (uint32_t i = 0; i < sd->textureCount; i++) {
+        tex[i].offset = (uint32_t)texels; tex[i].w = sd->textures[i].width; tex[i].h = sd->textures[i].height; tex[i].pad = 0;
+        texels += (size_t)sd->textures[i].width * sd->textures[i].height;
+        if (texels > 0xffffffffull) return c->fail(CRT_ERR_UNSUPPORTED, "texture pool exceeds 2^32 texels");
+    }
+    uint32_t* dTexels = nullptr;
+    HIPCK(c, hipMalloc((void**)&dTexels, texels * 4)); c->sceneAllocs.push_back(dTexels);
+    for (uint32_t i = 0; i < sd->textureCount; i++)
+        HIPCK(c, hipMemcpyAsync(dTexels + tex[i].offset, sd->textures[i].pixels, (size_t)tex[i].w * tex[i].h * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+
+    crt::Scene& s = c->hScene;
+    s.kind = sd->kind;
+    memcpy(s.lightInvT, sd->lightInvT, 48);
+    s.lightNrm[0] = -sd->lightT[1]; s.lightNrm[1] = -sd->lightT[5]; s.lightNrm[2] = -sd->lightT[9];   // Quad::GetNormal, primitives.h:363-367
+    s.lightSize = sd->lightSize;
+    memcpy(s.floorN, sd->floorN, 12); s.floorD = sd->floorD; s.floorInvto = sd->floorInvto;
+    s.floorTex = sd->floorTexture; s.skyTex = sd->skyTexture;
+    s.texels = dTexels;
+    int r;
+    if ((r = upload(c, tex, &s.tex))) return r;
+    if ((r = upload(c, mats, &s.mats))) return r;
+    if ((r = upload(c, pairs, &s.pairs))) return r;
+    if ((r = upload(c, leaf, &s.leaf))) return r;
+    if ((r = upload(c, shade, &s.shade))) return r;
+    if ((r = upload(c, objMat, &s.objMat))) return r;
+    if ((r = upload(c, tlas, &s.tlas))) return r;
+    if ((r = upload(c, inst, &s.inst))) return r;
+    s.rootRef = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot : rootRef0;
+    s.bvhStack = maxHeight + 2; s.tlasStack = (sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 2 : 0;
+    c->ldsBytes = (s.bvhStack + s.tlasStack) * 64u * 4u;
+    if (c->ldsBytes > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "tree height %u (+TLAS %u) needs %u bytes of LDS traversal stack per wave (> 64 KiB)", maxHeight, tlasHeight, c->ldsBytes);
+    HIPCK(c, hipMemcpyAsync(c->dScene, &c->hScene, sizeof(crt::Scene), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->haveScene = true;
+    return CRT_OK;
+}
+
+int crt_set_camera(crt_ctx* c, const float camPos[3], const float tl[3], const float tr[3], const float bl[3])
+{
+    if (!c || !camPos || !tl || !tr || !bl) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    memcpy(c->hScene.camPos, camPos, 12); memcpy(c->hScene.topLeft, tl, 12); memcpy(c->hScene.topRight, tr, 12); memcpy(c->hScene.bottomLeft, bl, 12);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpyAsync(c->dScene, &c->hScene, sizeof(crt::Scene), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+static int take_event(crt_ctx* c, std::vector<EventPair>& list, EventPair* out)
+{
+    EventPair ev;
+    if (c->evPool.empty()) {
+        HIPCK(c, hipEventCreate(&ev.a)); HIPCK(c, hipEventCreate(&ev.b));
+    } else { ev = c->evPool.back(); c->evPool.pop_back(); }
+    list.push_back(ev); *out = ev;
+    return 0;
+}
+
+int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
+{
+    if (!c) return CRT_ERR_INVALID;
+    if (!c->haveScene) return c->fail(CRT_ERR_STATE, "crt_render before crt_upload_scene");
+    if (passes < 1 || passes > 4) return c->fail(CRT_ERR_INVALID, "passes must be 1..4 (the reference's UI range, renderer.cpp:178)");
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    // recycle the previous render's events
+    for (auto& ev : c->evRender) c->evPool.push_back(ev);
+    for (auto& ev : c->evAcc) c->evPool.push_back(ev);
+    c->evRender.clear(); c->evAcc.clear();
+    if (c->tileCount == 0 || frames == 0) return CRT_OK;
+    const uint32_t maxF = (uint32_t)c->cfg.maxFramesPerLaunch;
+    const size_t need = (size_t)c->tileCount * 256u * (size_t)maxF * passes * 16u;
+    if (need > c->slabBytes) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (c->dSlab) { HIPCK(c, hipFree(c->dSlab)); c->dSlab = nullptr; c->slabBytes = 0; }
+        HIPCK(c, hipMalloc(&c->dSlab, need));
+        c->slabBytes = need;
+    }
+    for (uint32_t f0 = 0; f0 < frames; f0 += maxF) {
+        const uint32_t nf = (frames - f0 < maxF) ? frames - f0 : maxF;
+        EventPair ev; int r;
+        if ((r = take_event(c, c->evRender, &ev))) return r;
+        HIPCK(c, hipEventRecord(ev.a, c->stream));
+        HIPCK(c, crt_launch_render(c->dScene, c->dSlab, c->dCounters, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, c->stream));
+        HIPCK(c, hipEventRecord(ev.b, c->stream));
+        if ((r = take_event(c, c->evAcc, &ev))) return r;
+        HIPCK(c, hipEventRecord(ev.a, c->stream));
+        HIPCK(c, crt_launch_accumulate(c->dSlab, c->dAcc, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, (uint32_t)c->cfg.width, nf * passes, c->stream));
+        HIPCK(c, hipEventRecord(ev.b, c->stream));
+    }
+    return CRT_OK;
+}
+
+int crt_sync(crt_ctx* c)
+{
+    if (!c) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+int crt_clear(crt_ctx* c)
+{
+    if (!c) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMemsetAsync(c->dAcc, 0, (size_t)c->cfg.width * c->cfg.height * 16, c->stream));
+    return CRT_OK;
+}
+
+int crt_read_accumulator(crt_ctx* c, float* host)
+{
+    if (!c || !host) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMemcpyAsync(host, c->dAcc, (size_t)c->cfg.width * c->cfg.height * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+int crt_resolve_screen(crt_ctx* c, float scale, uint32_t* hostPixels, float* energy)
+{
+    if (!c) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    const int tiles = c->tilesX * c->tilesY;
+    HIPCK(c, crt_launch_resolve(c->dAcc, c->dPixels, c->dTileSums, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, (uint32_t)c->cfg.width, scale, c->stream));
+    if (hostPixels) HIPCK(c, hipMemcpyAsync(hostPixels, c->dPixels, (size_t)c->cfg.width * c->cfg.height * 4, hipMemcpyDeviceToHost, c->stream));
+    std::vector<float> sums(tiles);
+    HIPCK(c, hipMemcpyAsync(sums.data(), c->dTileSums, (size_t)tiles * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (energy) { float e = 0; for (int i = 0; i < tiles; i++) e += sums[i]; *energy = e; }   // renderer.cpp:155-157, tile order
+    return CRT_OK;
+}
+
+int crt_find_nearest(crt_ctx* c, const crt_ray* rays, crt_hit* hits, size_t n)
+{
+    if (!c || (n && (!rays || !hits))) return CRT_ERR_INVALID;
+    if (!c->haveScene) return c->fail(CRT_ERR_STATE, "crt_find_nearest before crt_upload_scene");
+    if (n == 0) return CRT_OK;
+    if (n > 0x7fffffffull) return c->fail(CRT_ERR_UNSUPPORTED, "at most 2^31-1 rays per call");
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    void *dR = nullptr, *dH = nullptr;
+    HIPCK(c, hipMalloc(&dR, n * sizeof(crt_ray)));
+    hipError_t e = hipMalloc(&dH, n * sizeof(crt_hit));
+    if (e != hipSuccess) { (void)hipFree(dR); return c->hip(e, "hipMalloc(hits)"); }
+    int rc = CRT_OK;
+    do {
+        if ((e = hipMemcpyAsync(dR, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, c->stream)) != hipSuccess) { rc = c->hip(e, "copy rays"); break; }
+        if ((e = crt_launch_find_nearest(c->dScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->stream)) != hipSuccess) { rc = c->hip(e, "launch find_nearest"); break; }
+        if ((e = hipMemcpyAsync(hits, dH, n * sizeof(crt_hit), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) { rc = c->hip(e, "copy hits"); break; }
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { rc = c->hip(e, "sync"); break; }
+    } while (0);
+    (void)hipFree(dR); (void)hipFree(dH);
+    return rc;
+}
+
+int crt_get_counters(crt_ctx* c, crt_counters* out)
+{
+    if (!c || !out) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMemcpyAsync(out, c->dCounters, sizeof(crt::Counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+int crt_reset_counters(crt_ctx* c)
+{
+    if (!c) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMemsetAsync(c->dCounters, 0, sizeof(crt::Counters), c->stream));
+    return CRT_OK;
+}
+
+int crt_get_timing(crt_ctx* c, crt_timing* out)
+{
+    if (!c || !out) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    memset(out, 0, sizeof(*out));
+    for (auto& ev : c->evRender) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->render_kernel_ms += ms; }
+    for (auto& ev : c->evAcc) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->resolve_kernel_ms += ms; }
+    out->render_launches = (uint32_t)c->evRender.size();
+    return CRT_OK;
+}
+
+int crt_bind_accumulator(crt_ctx* c, void* p)
+{
+    if (!c) return CRT_ERR_INVALID;
+    if (p && ((uintptr_t)p & 15u)) return c->fail(CRT_ERR_INVALID, "accumulator pointer must be 16-byte aligned");
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->dAcc = p ? p : c->dAccOwned;
+    return CRT_OK;
+}
+
+int crt_accumulator_device_ptr(crt_ctx* c, void** p)
+{
+    if (!c || !p) return CRT_ERR_INVALID;
+    *p = c->dAcc; return CRT_OK;
+}
+
+} // extern "C"

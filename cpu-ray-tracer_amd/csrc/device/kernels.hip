@@ -1,0 +1,591 @@
+// kernels.hip — hand-written gfx950 (CDNA4) kernels of the path-tracing hot path.
+//
+//   render_tiles_kernel   one 64-lane wavefront per 16x16 image tile; lane f owns the RNG stream of frame f of that
+//                         tile (the reference seeds one xorshift32 stream per (tile, frame) and consumes it serially
+//                         over the tile's 256 pixels — "3. PathTracer/renderer.cpp":117-131).  Every loop iteration
+//                         of a lane traces exactly one ray (ray-gen / traverse / shade phases, path regeneration when a
+//                         path ends), so the wave never idles on short paths.  Traversal stacks are per-lane columns
+//                         in LDS.  Each finished path writes its radiance sample to the sample slab in HBM.
+//   accumulate_kernel     adds the slab's samples to the float4 accumulator in frame order (bit-exact with the
+//                         reference's `accumulator[..] +=` order, renderer.cpp:124) — no float atomics anywhere.
+//   find_nearest_kernel   scene.FindNearest for a ray buffer (parity / query entry).
+//   resolve_kernel        screen pixels + per-tile energy sums (renderer.cpp:119,127-129).
+//
+// Numerics: compiled with -ffp-contract=off; only IEEE + - * / sqrt, so results are bit-identical with a scalar
+// CPU evaluation of the same expressions.  min/max follow the reference's std::min/std::max operand order.
+// No MFMA: the path is pointer chasing + slab / Möller–Trumbore tests.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "layout.h"
+
+namespace crt {
+
+// ------------------------------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float b) { return mk3(a.x * b, a.y * b, a.z * b); }
+__device__ __forceinline__ f3 operator*(float b, f3 a) { return mk3(b * a.x, b * a.y, b * a.z); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ f3 normalize3(f3 v) { float inv = 1.0f / __builtin_sqrtf(dot3(v, v)); return v * inv; }
+__device__ __forceinline__ float min_std(float a, float b) { return (b < a) ? b : a; }   // std::min(a,b)
+__device__ __forceinline__ float max_std(float a, float b) { return (a < b) ? b : a; }   // std::max(a,b)
+__device__ __forceinline__ float min_tm(float a, float b) { return a < b ? a : b; }       // tmplmath fminf
+__device__ __forceinline__ float max_tm(float a, float b) { return a > b ? a : b; }       // tmplmath fmaxf
+__device__ __forceinline__ float clamp_tm(float f, float a, float b) { return max_tm(a, min_tm(f, b)); }
+__device__ __forceinline__ int clampi(int f, int a, int b) { int m = (b < f) ? b : f; return (a < m) ? m : a; }
+__device__ __forceinline__ float asf(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
+
+#define CRT_PI 3.14159265358979323846264f
+#define CRT_INVPI 0.31830988618379067153777f
+#define CRT_INV2PI 0.15915494309189533576888f
+#define CRT_EPS 0.001f
+
+// deterministic exp / atan2 / acos: same formulas, same operation order as the checker's restatement (DESIGN.md "numerics")
+__device__ float crt_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return asf(0x7f800000u);
+    if (x < -103.972084045410f) return 0.0f;
+    float fk = __builtin_floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - fk * 0.693359375f;
+    r = r - fk * -2.12194440e-4f;
+    float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * z + r;
+    p = p + 1.0f;
+    int k = (int)fk;
+    int k1 = k / 2, k2 = k - k1;
+    float s1 = asf((uint32_t)(k1 + 127) << 23), s2 = asf((uint32_t)(k2 + 127) << 23);
+    return p * s1 * s2;
+}
+__device__ float crt_atan_pos(float x)
+{
+    float y0, t;
+    if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; t = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = (x - 1.0f) / (x + 1.0f); }
+    else { y0 = 0.0f; t = x; }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    p = p * z * t + t;
+    return y0 + p;
+}
+__device__ float crt_atan2f(float y, float x)
+{
+    if (x != x || y != y) return x + y;
+    uint32_t sy = asu(y) & 0x80000000u, sx = asu(x) & 0x80000000u;
+    float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    float r;
+    const float inf = asf(0x7f800000u);
+    if (ay == 0.0f) r = sx ? CRT_PI : 0.0f;
+    else if (ax == 0.0f) r = 1.5707963267948966f;
+    else if (ax == inf && ay == inf) r = sx ? 2.356194490192345f : 0.7853981633974483f;
+    else { float a = crt_atan_pos(ay / ax); r = sx ? (CRT_PI - a) : a; }
+    return asf(asu(r) | sy);
+}
+__device__ float crt_asin_small(float x)
+{
+    float z = x * x;
+    float p = 4.2163199048e-2f;
+    p = p * z + 2.4181311049e-2f;
+    p = p * z + 4.5470025998e-2f;
+    p = p * z + 7.4953002686e-2f;
+    p = p * z + 1.6666752422e-1f;
+    p = p * z * x + x;
+    return p;
+}
+__device__ float crt_acosf(float x)
+{
+    if (x != x) return x;
+    if (x > 1.0f || x < -1.0f) return asf(0x7fc00000u);
+    if (x > 0.5f) { float s = __builtin_sqrtf(0.5f * (1.0f - x)); return 2.0f * crt_asin_small(s); }
+    if (x < -0.5f) { float s = __builtin_sqrtf(0.5f * (1.0f + x)); return CRT_PI - 2.0f * crt_asin_small(s); }
+    return 1.5707963267948966f - crt_asin_small(x);
+}
+
+// RNG: WangHash seed + xorshift32 (template/tmplmath.cpp:5-16, 27-34)
+__device__ __forceinline__ uint32_t wang_hash(uint32_t s)
+{
+    s = (s ^ 61u) ^ (s >> 16); s *= 9u; s = s ^ (s >> 4); s *= 0x27d4eb2du; s = s ^ (s >> 15); return s;
+}
+__device__ __forceinline__ uint32_t init_seed(uint32_t base) { return wang_hash((base + 1u) * 17u); }
+__device__ __forceinline__ float rnd(uint32_t& s)
+{
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+    return (float)s * 2.3283064365387e-10f;
+}
+
+struct Hit { float t, u, v; int objIdx, triIdx; };
+struct Cnt { uint32_t rays, primary, interior, leaf, tri, tlas, visits, meshhits; };
+
+__device__ __forceinline__ float4 ld4(const void* p) { return *reinterpret_cast<const float4*>(p); }
+
+// slab test, infra/bvh.cpp:181-190
+__device__ __forceinline__ float slab(float4 lo, float4 hi, f3 O, f3 rD, float tray)
+{
+    float tx1 = (lo.x - O.x) * rD.x, tx2 = (hi.x - O.x) * rD.x;
+    float tmin = min_std(tx1, tx2), tmax = max_std(tx1, tx2);
+    float ty1 = (lo.y - O.y) * rD.y, ty2 = (hi.y - O.y) * rD.y;
+    tmin = max_std(tmin, min_std(ty1, ty2)); tmax = min_std(tmax, max_std(ty1, ty2));
+    float tz1 = (lo.z - O.z) * rD.z, tz2 = (hi.z - O.z) * rD.z;
+    tmin = max_std(tmin, min_std(tz1, tz2)); tmax = min_std(tmax, max_std(tz1, tz2));
+    return (tmax >= tmin && tmin < tray && tmax > 0) ? tmin : 1e30f;
+}
+
+// ordered stack traversal of one BVH (infra/bvh.cpp:224-258); stack = this lane's LDS column (stride 64 dwords)
+template <bool COUNT>
+__device__ __forceinline__ void traverse_bvh(const NodePair* __restrict__ pairs, const LeafTri* __restrict__ leaf, uint32_t rootRef,
+                                             f3 O, f3 D, f3 rD, Hit& h, uint32_t* stk, Cnt& cn, int& traversed, int& tested)
+{
+    uint32_t cur = rootRef, sp = 0;
+    for (;;) {
+        traversed++;
+        if (cur & kInteriorFlag) {
+            if (COUNT) cn.interior++;
+            const char* p = reinterpret_cast<const char*>(pairs + (cur & 0x7fffffffu));
+            float4 alo = ld4(p), ahi = ld4(p + 16), blo = ld4(p + 32), bhi = ld4(p + 48);
+            float d1 = slab(alo, ahi, O, rD, h.t), d2 = slab(blo, bhi, O, rD, h.t);
+            uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
+            if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+            if (d1 == 1e30f) {
+                if (sp == 0) break;
+                cur = stk[(--sp) * 64];
+            } else {
+                cur = r1;
+                if (d2 != 1e30f) { stk[sp * 64] = r2; sp++; }
+            }
+        } else {
+            if (COUNT) cn.leaf++;
+            uint32_t first = cur & 0xffffffu, cnt = cur >> 24;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const char* p = reinterpret_cast<const char*>(leaf + first + i);
+                float4 a = ld4(p), b = ld4(p + 16), c = ld4(p + 32);
+                tested++;
+                if (COUNT) cn.tri++;
+                // Möller–Trumbore, infra/bvh.cpp:203-222
+                f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+                f3 hh = cross3(D, e2);
+                float det = dot3(e1, hh);
+                if (det > -0.0001f && det < 0.0001f) continue;
+                float f = 1 / det;
+                f3 s = O - v0;
+                float u = f * dot3(s, hh);
+                if (u < 0 || u > 1) continue;
+                f3 q = cross3(s, e1);
+                float v = f * dot3(D, q);
+                if (v < 0 || u + v > 1) continue;
+                float t = f * dot3(e2, q);
+                if (t > 0.0001f && t < h.t) { h.t = t; h.u = u; h.v = v; h.triIdx = (int)asu(a.w); h.objIdx = (int)asu(b.w); }
+            }
+            if (sp == 0) break;
+            cur = stk[(--sp) * 64];
+        }
+    }
+}
+
+// scene.FindNearest: light quad, floor plane, then BVH or TLAS (file_scene.cpp:170-175, tlas_file_scene.cpp:201-206)
+template <bool COUNT>
+__device__ __forceinline__ void find_nearest(const Scene* __restrict__ sc, f3 O, f3 D, f3 rD, Hit& h, uint32_t* stk, Cnt& cn,
+                                             int& traversed, int& tested)
+{
+    cn.rays++;
+    {   // Quad::Intersect, template/primitives.h:331-346
+        const float* c = sc->lightInvT;
+        const float Oy = c[4] * O.x + c[5] * O.y + c[6] * O.z + c[7];
+        const float Dy = c[4] * D.x + c[5] * D.y + c[6] * D.z;
+        const float t = Oy / -Dy;
+        if (t < h.t && t > 0) {
+            const float Ox = c[0] * O.x + c[1] * O.y + c[2] * O.z + c[3];
+            const float Oz = c[8] * O.x + c[9] * O.y + c[10] * O.z + c[11];
+            const float Dx = c[0] * D.x + c[1] * D.y + c[2] * D.z;
+            const float Dz = c[8] * D.x + c[9] * D.y + c[10] * D.z;
+            const float Ix = Ox + t * Dx, Iz = Oz + t * Dz;
+            const float size = sc->lightSize;
+            if (Ix > -size && Ix < size && Iz > -size && Iz < size) { h.t = t; h.objIdx = 0; }
+        }
+    }
+    {   // Plane::Intersect, template/primitives.h:107-111
+        f3 N = mk3(sc->floorN[0], sc->floorN[1], sc->floorN[2]);
+        float t = -(dot3(O, N) + sc->floorD) / (dot3(D, N));
+        if (t < h.t && t > 0) { h.t = t; h.objIdx = 1; }
+    }
+    if (sc->kind == 0) {
+        traverse_bvh<COUNT>(sc->pairs, sc->leaf, sc->rootRef, O, D, rD, h, stk, cn, traversed, tested);
+    } else {
+        // TLASBVH::Intersect, infra/tlas_bvh.cpp:83-111.  packed ref: leaf = flag | BLAS, interior = leftRight
+        uint32_t* tstk = stk + sc->bvhStack * 64;
+        const TlasNode* __restrict__ tl = sc->tlas;
+        uint32_t cur = sc->rootRef, sp = 0;
+        for (;;) {
+            traversed++;
+            if (COUNT) cn.tlas++;
+            if (cur & kInteriorFlag) {
+                // BLASBVH::Intersect, infra/blas_bvh.cpp:376-389: ray to object space through invT, SSE summation order
+                if (COUNT) cn.visits++;
+                const Instance* in = sc->inst + (cur & 0xffffu);
+                float4 r0 = ld4(in->invT), r1 = ld4(in->invT + 4), r2 = ld4(in->invT + 8);
+                f3 Oo = mk3((O.x * r0.x + O.y * r0.y) + (O.z * r0.z + 1.0f * r0.w),
+                            (O.x * r1.x + O.y * r1.y) + (O.z * r1.z + 1.0f * r1.w),
+                            (O.x * r2.x + O.y * r2.y) + (O.z * r2.z + 1.0f * r2.w));
+                f3 Do = mk3((D.x * r0.x + D.y * r0.y) + D.z * r0.z,
+                            (D.x * r1.x + D.y * r1.y) + D.z * r1.z,
+                            (D.x * r2.x + D.y * r2.y) + D.z * r2.z);
+                f3 rDo = mk3(1 / Do.x, 1 / Do.y, 1 / Do.z);
+                traverse_bvh<COUNT>(sc->pairs + in->pairBase, sc->leaf + in->leafBase, in->rootRef, Oo, Do, rDo, h, stk, cn, traversed, tested);
+                if (sp == 0) break;
+                cur = tstk[(--sp) * 64];
+            } else {
+                const char* p1 = reinterpret_cast<const char*>(tl + (cur & 0xffffu));
+                const char* p2 = reinterpret_cast<const char*>(tl + (cur >> 16));
+                float4 alo = ld4(p1), ahi = ld4(p1 + 16), blo = ld4(p2), bhi = ld4(p2 + 16);
+                float d1 = slab(alo, ahi, O, rD, h.t), d2 = slab(blo, bhi, O, rD, h.t);
+                uint32_t lr1 = asu(alo.w), lr2 = asu(blo.w);
+                uint32_t r1 = lr1 ? lr1 : (kInteriorFlag | asu(ahi.w));
+                uint32_t r2 = lr2 ? lr2 : (kInteriorFlag | asu(bhi.w));
+                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+                if (d1 == 1e30f) {
+                    if (sp == 0) break;
+                    cur = tstk[(--sp) * 64];
+                } else {
+                    cur = r1;
+                    if (d2 != 1e30f) { tstk[sp * 64] = r2; sp++; }
+                }
+            }
+        }
+    }
+    if (h.objIdx >= 2) cn.meshhits++;
+}
+
+// Texture::Sample, template/texture.h:61-96
+__device__ __forceinline__ f3 tex_sample(const Scene* __restrict__ sc, int id, float u, float v)
+{
+    const TexDesc td = sc->tex[id];
+    u = clamp_tm(u, 0.0f, 1.0f);
+    v = 1 - clamp_tm(v, 0.0f, 1.0f);
+    int x = (int)(u * td.w), y = (int)(v * td.h);
+    x = clampi(x, 0, td.w - 1); y = clampi(y, 0, td.h - 1);
+    uint32_t p = sc->texels[(size_t)td.offset + (size_t)x + (size_t)y * (size_t)td.w];
+    const float s = 1 / 255.0f;
+    return mk3(((p >> 16) & 0xFF) * s, ((p >> 8) & 0xFF) * s, (p & 0xFF) * s);
+}
+
+// GetSkyColor, infra/scene/file_scene.cpp:142-154
+__device__ __forceinline__ f3 sky_color(const Scene* __restrict__ sc, f3 D)
+{
+    float phi = crt_atan2f(-D.z, D.x) + CRT_PI;
+    float theta = crt_acosf(-D.y);
+    return tex_sample(sc, sc->skyTex, phi * CRT_INV2PI, theta * CRT_INVPI);
+}
+
+// One bounce of Renderer::Sample ("3. PathTracer/renderer.cpp":50-100) after FindNearest.
+// Returns true when the path ends (L = terminal radiance); otherwise writes the throughput factor of this
+// depth and the continuation ray.
+__device__ __forceinline__ bool shade(const Scene* __restrict__ sc, const Hit& h, f3& O, f3& D, f3& rD, bool& inside,
+                                      int depth, uint32_t& seed, f3& factor, f3& L)
+{
+    if (h.objIdx == -1) { L = sky_color(sc, D); return true; }
+    if (depth >= sc->depthLimit) { L = mk3(0, 0, 0); return true; }
+    if (h.objIdx == 0) { L = mk3(24, 24, 22); return true; }        // light: GetLightColor (file_scene.cpp:164-167)
+    f3 I = O + h.t * D;
+    f3 N; float tu = 0, tv = 0; int mat;
+    if (h.objIdx == 1) {                                              // floor: Plane::GetNormal / GetUV (primitives.h:112-133)
+        N = mk3(sc->floorN[0], sc->floorN[1], sc->floorN[2]);
+        if (N.y == 1) {
+            float u = I.x, v = I.z;
+            u *= sc->floorInvto; v *= sc->floorInvto;
+            tu = u - __builtin_floorf(u); tv = v - __builtin_floorf(v);
+        }
+        mat = 1;
+    } else {                                                          // mesh: GetNormal / GetUV (bvh.cpp:290-305, blas_bvh.cpp:391-406)
+        uint32_t base = 0; const Instance* in = nullptr;
+        if (sc->kind != 0) { in = sc->inst + (h.objIdx - 2); base = in->shadeBase; }
+        const char* p = reinterpret_cast<const char*>(sc->shade + base + (uint32_t)h.triIdx);
+        float4 a = ld4(p), b = ld4(p + 16), c = ld4(p + 32), d = ld4(p + 48);
+        f3 n0 = mk3(a.x, a.y, a.z), n1 = mk3(a.w, b.x, b.y), n2 = mk3(b.z, b.w, c.x);
+        float w = 1 - h.u - h.v;
+        f3 Nn = w * n0 + h.u * n1 + h.v * n2;
+        tu = w * c.y + h.u * c.w + h.v * d.y;
+        tv = w * c.z + h.u * d.x + h.v * d.z;
+        if (sc->kind == 0) {
+            N = normalize3(Nn);
+            mat = sc->objMat[(int)asu(d.w) - 2] + 2;
+        } else {
+            float4 r0 = ld4(in->T), r1 = ld4(in->T + 4), r2 = ld4(in->T + 8);
+            f3 Nt = mk3(r0.x * Nn.x + r0.y * Nn.y + r0.z * Nn.z + r0.w * 0.0f,
+                        r1.x * Nn.x + r1.y * Nn.y + r1.z * Nn.z + r1.w * 0.0f,
+                        r2.x * Nn.x + r2.y * Nn.y + r2.z * Nn.z + r2.w * 0.0f);
+            N = normalize3(Nt);
+            mat = in->matIdx + 2;
+        }
+    }
+    if (dot3(N, D) > 0) N = -N;
+    const Material m = sc->mats[mat];
+    f3 albedo = (m.tex >= 0) ? tex_sample(sc, m.tex, tu, tv) : mk3(1.0f, 1.0f, 1.0f);
+    f3 medium = mk3(1, 1, 1);
+    if (inside) {
+        f3 ab = mk3(m.absorption[0], m.absorption[1], m.absorption[2]) * -h.t;
+        medium = mk3(crt_expf(ab.x), crt_expf(ab.y), crt_expf(ab.z));
+    }
+    float r = rnd(seed);
+    f3 R;
+    bool newInside = false;
+    if (r < m.reflectivity) {                                         // HandleMirror, renderer.cpp:20-25
+        R = D - 2.0f * N * dot3(N, D);
+        factor = albedo * medium;
+    } else if (r < m.reflectivity + m.refractivity) {                 // HandleDielectric, renderer.cpp:27-45
+        R = D - 2.0f * N * dot3(N, D);
+        float n1 = inside ? 1.2f : 1, n2 = inside ? 1 : 1.2f;
+        float eta = n1 / n2, cosi = dot3(-D, N);
+        float cost2 = 1.0f - eta * eta * (1 - cosi * cosi);
+        if (cost2 > 0) {
+            float a = n1 - n2, b = n1 + n2, R0 = (a * a) / (b * b), c = 1 - cosi;
+            float Fr = R0 + (1 - R0) * (c * c * c * c * c);
+            f3 T = eta * D + ((eta * cosi - __builtin_sqrtf(__builtin_fabsf(cost2))) * N);
+            if (rnd(seed) > Fr) { R = T; newInside = !inside; }
+        }
+        factor = albedo * medium;
+    } else {                                                          // diffuse, renderer.cpp:93-99; tmplmath.h:535-544
+        f3 Rr;
+        do {
+            float rz = rnd(seed) * 2 - 1;                             // draw order pinned z, y, x
+            float ry = rnd(seed) * 2 - 1;
+            float rx = rnd(seed) * 2 - 1;
+            Rr = mk3(rx, ry, rz);
+        } while (dot3(Rr, Rr) > 1);
+        if (dot3(Rr, N) < 0) Rr = Rr * -1.0f;
+        R = normalize3(Rr);
+        f3 brdf = albedo * CRT_INVPI;
+        factor = medium * brdf * 2.0f * CRT_PI * dot3(R, N);
+    }
+    O = I + R * CRT_EPS; D = R; rD = mk3(1 / R.x, 1 / R.y, 1 / R.z);
+    inside = newInside;
+    return false;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// render_tiles_kernel: grid = tiles owned by this ctx, block = one wavefront.
+// slab layout: float4 [tileLocal][pixel 0..255][sample 0..S), S = frames*passes, sample = frame*passes + pass
+// ------------------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(64) void render_tiles_kernel(const Scene* __restrict__ sc, float4* __restrict__ slab,
+                                                           Counters* __restrict__ counters,
+                                                           uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
+                                                           uint32_t sppFirst, uint32_t frames, uint32_t passes)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    // XCD-aware order: consecutive tiles (which share BVH subtrees and texture rows) go to the same XCD's L2.
+    // blocks are dealt round-robin over the 8 XCDs, so block b lands on XCD b % 8.
+    uint32_t b = blockIdx.x, nb = gridDim.x;
+    uint32_t per = (nb + 7u) / 8u;
+    uint32_t tl = (b % 8u) * per + b / 8u;
+    if (nb % 8u != 0) tl = b;                        // bijective only when the grid is a multiple of 8
+    if (tl >= tileCount) return;
+    const uint32_t tile = tileFirst + tl * tileStride;
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    uint32_t* stk = lds + lane;
+
+    Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
+    const bool active = lane < frames;
+    const uint32_t S = frames * passes;
+    const int W = sc->W;
+    const f3 camPos = mk3(sc->camPos[0], sc->camPos[1], sc->camPos[2]);
+    const f3 TL = mk3(sc->topLeft[0], sc->topLeft[1], sc->topLeft[2]);
+    const f3 TR = mk3(sc->topRight[0], sc->topRight[1], sc->topRight[2]);
+    const f3 BL = mk3(sc->bottomLeft[0], sc->bottomLeft[1], sc->bottomLeft[2]);
+
+    if (active) {
+        const uint32_t spp = sppFirst + lane * passes;
+        uint32_t seed = init_seed(tx + ty * (uint32_t)W + spp * 1799u);            // renderer.cpp:120
+        const uint32_t items = 256u * passes;                                         // (pixel, pass) pairs in stream order
+        uint32_t item = 0;
+        bool needGen = true;
+        f3 O = camPos, D = camPos, rD = camPos; bool inside = false; int depth = 0;
+        f3 F0 = camPos, F1 = camPos, F2 = camPos, F3 = camPos, F4 = camPos;           // throughput factors of depths 0..4
+        while (item < items) {
+            if (needGen) {
+                const uint32_t pix = item / passes;
+                const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
+                const float jy = rnd(seed);                                           // pinned: first draw is the y jitter
+                const float jx = rnd(seed);
+                const float u = ((float)x + jx) * sc->invW, v = ((float)y + jy) * sc->invH;   // camera.h:23-30
+                const f3 P = TL + u * (TR - TL) + v * (BL - TL);
+                O = camPos; D = normalize3(P - camPos); rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
+                inside = false; depth = 0; needGen = false;
+                cn.primary++;
+            }
+            Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+            int traversed = 0, tested = 0;
+            find_nearest<COUNT>(sc, O, D, rD, h, stk, cn, traversed, tested);
+            f3 factor, L;
+            const bool done = shade(sc, h, O, D, rD, inside, depth, seed, factor, L);
+            if (!done) {
+                if (depth == 0) F0 = factor; else if (depth == 1) F1 = factor; else if (depth == 2) F2 = factor;
+                else if (depth == 3) F3 = factor; else F4 = factor;
+                depth++;
+            } else {
+                // unwind the recursion: innermost factor first (albedo*medium*Sample(...) multiplies on return)
+                if (depth > 4) L = F4 * L;
+                if (depth > 3) L = F3 * L;
+                if (depth > 2) L = F2 * L;
+                if (depth > 1) L = F1 * L;
+                if (depth > 0) L = F0 * L;
+                const uint32_t pix = item / passes, pass = item - pix * passes;
+                slab[((size_t)tl * 256u + pix) * S + (size_t)lane * passes + pass] = make_float4(L.x, L.y, L.z, 0.0f);
+                item++;
+                needGen = true;
+            }
+        }
+    }
+    // wave-level reduction of the counters, one atomic per counter per wave
+    uint32_t vals[8] = {cn.rays, cn.primary, cn.interior, cn.leaf, cn.tri, cn.tlas, cn.visits, cn.meshhits};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (!COUNT && i >= 2 && i != 7) continue;
+        uint32_t s = wave_sum(vals[i]);
+        if (lane == 0 && s) atomicAdd(&counters->v[i], (unsigned long long)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// accumulate_kernel: accumulator[pixel] += slab samples, in sample (= frame, pass) order.  One thread per pixel of
+// the owned tiles; 64 consecutive threads = 4 pixel rows of one tile.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ slab, float4* __restrict__ acc,
+                                                          uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
+                                                          uint32_t W, uint32_t S)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tl = idx >> 8, pix = idx & 255u;
+    if (tl >= tileCount) return;
+    const uint32_t tile = tileFirst + tl * tileStride;
+    const uint32_t x = (tile % tilesX) * 16u + (pix & 15u), y = (tile / tilesX) * 16u + (pix >> 4);
+    const float4* s = slab + (size_t)idx * S;
+    float4 a = acc[x + (size_t)y * W];
+    for (uint32_t i = 0; i < S; i++) {
+        const float4 v = s[i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    acc[x + (size_t)y * W] = a;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// find_nearest_kernel: one ray per lane
+// ------------------------------------------------------------------------------------------------------------
+struct RayIn { float O[3]; float D[3]; int32_t inside; };
+struct HitOut { float t, u, v; int32_t objIdx, triIdx, traversed, tested; };
+
+__global__ __launch_bounds__(64) void find_nearest_kernel(const Scene* __restrict__ sc, const RayIn* __restrict__ rays,
+                                                           HitOut* __restrict__ hits, uint32_t n, Counters* __restrict__ counters)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64u + lane;
+    Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
+    if (i < n) {
+        const RayIn r = rays[i];
+        f3 O = mk3(r.O[0], r.O[1], r.O[2]), D = mk3(r.D[0], r.D[1], r.D[2]);
+        f3 rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);                                       // Ray ctor, template/ray.h:15-24
+        Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+        int traversed = 0, tested = 0;
+        find_nearest<true>(sc, O, D, rD, h, lds + lane, cn, traversed, tested);
+        HitOut o; o.t = h.t; o.u = h.u; o.v = h.v; o.objIdx = h.objIdx; o.triIdx = h.triIdx; o.traversed = traversed; o.tested = tested;
+        hits[i] = o;
+    }
+    uint32_t vals[8] = {cn.rays, cn.primary, cn.interior, cn.leaf, cn.tri, cn.tlas, cn.visits, cn.meshhits};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t s = wave_sum(vals[k]);
+        if (lane == 0 && s) atomicAdd(&counters->v[k], (unsigned long long)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// resolve_kernel: one thread per owned tile; pixels in ProcessTile order so the per-tile energy sum is bit-exact
+// (renderer.cpp:119,127-129; RGBF32_to_RGB8 scalar branch, template/precomp.h:336-340)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void resolve_kernel(const float4* __restrict__ acc, uint32_t* __restrict__ pixels, float* __restrict__ tileSums,
+                                                      uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
+                                                      uint32_t W, float scale)
+{
+    const uint32_t tl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tl >= tileCount) return;
+    const uint32_t tile = tileFirst + tl * tileStride;
+    const uint32_t x0 = (tile % tilesX) * 16u, y0 = (tile / tilesX) * 16u;
+    float sum = 0;
+    for (uint32_t v = 0; v < 16; v++) for (uint32_t u = 0; u < 16; u++) {
+        const size_t i = (x0 + u) + (size_t)(y0 + v) * W;
+        const float4 a = acc[i];
+        const float px = a.x * scale, py = a.y * scale, pz = a.z * scale;
+        sum += px + py + pz;
+        const uint32_t r = (uint32_t)(255.0f * min_std(1.0f, px)), g = (uint32_t)(255.0f * min_std(1.0f, py)), bb = (uint32_t)(255.0f * min_std(1.0f, pz));
+        pixels[i] = (r << 16) + (g << 8) + bb;
+    }
+    tileSums[tile] = sum;
+}
+
+} // namespace crt
+
+// ------------------------------------------------------------------------------------------------------------
+// launch wrappers (called from abi.cpp)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, uint32_t tileFirst, uint32_t tileStride,
+                                        uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst, uint32_t frames, uint32_t passes,
+                                        uint32_t ldsBytes, int collectStats, hipStream_t stream)
+{
+    if (tileCount == 0 || frames == 0) return hipSuccess;
+    dim3 grid(tileCount), block(64);
+    if (collectStats)
+        hipLaunchKernelGGL(crt::render_tiles_kernel<true>, grid, block, ldsBytes, stream, sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes);
+    else
+        hipLaunchKernelGGL(crt::render_tiles_kernel<false>, grid, block, ldsBytes, stream, sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t crt_launch_accumulate(const void* slab, void* acc, uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount,
+                                            uint32_t tilesX, uint32_t W, uint32_t S, hipStream_t stream)
+{
+    if (tileCount == 0 || S == 0) return hipSuccess;
+    dim3 grid(tileCount), block(256);
+    hipLaunchKernelGGL(crt::accumulate_kernel, grid, block, 0, stream, (const float4*)slab, (float4*)acc, tileFirst, tileStride, tileCount, tilesX, W, S);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t crt_launch_find_nearest(const crt::Scene* sc, const void* rays, void* hits, uint32_t n, crt::Counters* counters,
+                                              uint32_t ldsBytes, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    dim3 grid((n + 63u) / 64u), block(64);
+    hipLaunchKernelGGL(crt::find_nearest_kernel, grid, block, ldsBytes, stream, sc, (const crt::RayIn*)rays, (crt::HitOut*)hits, n, counters);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t crt_launch_resolve(const void* acc, uint32_t* pixels, float* tileSums, uint32_t tileFirst, uint32_t tileStride,
+                                         uint32_t tileCount, uint32_t tilesX, uint32_t W, float scale, hipStream_t stream)
+{
+    if (tileCount == 0) return hipSuccess;
+    dim3 grid((tileCount + 63u) / 64u), block(64);
+    hipLaunchKernelGGL(crt::resolve_kernel, grid, block, 0, stream, (const float4*)acc, pixels, tileSums, tileFirst, tileStride, tileCount, tilesX, W, scale);
+    return hipGetLastError();
+}

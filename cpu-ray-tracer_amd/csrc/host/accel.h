@@ -1,0 +1,79 @@
+// accel.h — CPU-side acceleration structures of the host front: BVH (single level), BLASBVH (per model, instanced)
+// and TLASBVH (top level).  Same public surface as the reference classes (infra/bvh.h:28-43, infra/blas_bvh.h:36-57,
+// infra/tlas_bvh.h:22-31): Build(), public bvhNodes / triangles / triangleIndices / nodesUsed / T / invT / blas.
+// The build runs on the CPU and must reproduce the reference's node numbering and triangle order exactly — the GPU
+// layout is derived from these arrays (crt_upload_scene).  Traversal lives on the GPU; Intersect() is not provided here.
+#pragma once
+#include "../../../include/crt_abi.h"
+#include "hmath.h"
+
+#include <string>
+#include <vector>
+
+namespace crt {
+
+typedef crt_tri Tri;           // 112-byte reference layout
+typedef crt_bvh_node BVHNode;  // 32-byte reference layout
+typedef crt_tlas_node TLASBVHNode;
+
+struct MeshCorners {           // tinyobj-resolved corners, three per triangle (positions, normals, uvs; zeros when absent)
+    std::vector<float> pos, nrm, uv;
+    size_t count() const { return pos.size() / 3; }
+};
+
+// binned-SAH builder shared by BVH and BLASBVH (the reference duplicates the code: bvh.cpp:4-178, blas_bvh.cpp:82-256)
+void BuildSAH(std::vector<Tri>& triangles, std::vector<BVHNode>& nodes, std::vector<uint32_t>& triangleIndices, uint32_t& nodesUsed, uint32_t& maxDepth);
+
+class BVH {
+public:
+    void Build() { BuildSAH(triangles, bvhNodes, triangleIndices, nodesUsed, maxDepth); }
+    int GetTriangleCount() const { return (int)triangles.size(); }
+    int objIdx = -1;
+    std::vector<BVHNode> bvhNodes;
+    std::vector<Tri> triangles;
+    std::vector<uint32_t> triangleIndices;
+    uint32_t rootNodeIdx = 0, nodesUsed = 1;
+    uint32_t maxDepth = 0;
+};
+
+class BLASBVH {
+public:
+    BLASBVH() = default;
+    // infra/blas_bvh.cpp:4-80: de-duplicated vertices -> triangles with the scale baked in, Build(), SetTransform(T)
+    BLASBVH(int idx, const MeshCorners& mesh, const mat4& transform, const mat4& scaleMat);
+    void Build() { BuildSAH(triangles, bvhNodes, triangleIndices, nodesUsed, maxDepth); }
+    void SetTransform(const mat4& transform);
+    int GetTriangleCount() const { return (int)triangles.size(); }
+    int objIdx = -1, matIdx = -1;
+    std::vector<BVHNode> bvhNodes;
+    std::vector<Tri> triangles;
+    std::vector<uint32_t> triangleIndices;
+    uint32_t rootNodeIdx = 0, nodesUsed = 1;
+    aabb worldBounds;
+    mat4 T, invT;
+    uint32_t maxDepth = 0;
+};
+
+class TLASBVH {
+public:
+    TLASBVH() = default;
+    explicit TLASBVH(const std::vector<BLASBVH*>& bvhList);
+    void Build();
+    std::vector<TLASBVHNode> tlasNode;     // 2 * blasCount entries (reference keeps this private; exposed for the upload)
+    uint32_t nodesUsed = 0, blasCount = 0;
+    std::vector<BLASBVH*> blas;
+};
+
+// Model (infra/model.{h,cpp}): de-duplicated vertices of one OBJ + its world transform, for the single-BVH FileScene
+class Model {
+public:
+    Model() = default;
+    Model(int idx, const MeshCorners& mesh, const mat4& transform);
+    void AppendTriangles(std::vector<Tri>& triangles) const;
+    int objIdx = -1, matIdx = -1;
+    std::vector<float> positions, normals, uvs;     // unique vertices (xyz, xyz, uv)
+    std::vector<uint32_t> indices;
+    mat4 T, invT;
+};
+
+} // namespace crt

@@ -1,0 +1,158 @@
+// host_abi.cpp — C wrappers (include/crt_host.h) around the C++ host front.  Exceptions stop here.
+#include "../../../include/crt_host.h"
+#include "scene.h"
+
+#include <cstdlib>
+#include <string>
+
+using namespace crt;
+
+namespace { thread_local std::string g_err; }
+
+struct crt_host_scene { BaseScene* scene = nullptr; FileScene* file = nullptr; TLASFileScene* tlas = nullptr; };
+struct crt_host_renderer { Renderer* r = nullptr; };
+
+#define GUARD_BEGIN try {
+#define GUARD_END(code) } catch (const std::exception& e) { g_err = e.what(); return code; } catch (...) { g_err = "unknown exception"; return code; }
+
+extern "C" {
+
+const char* crt_host_last_error(void) { return g_err.c_str(); }
+
+int crt_host_scene_load(const char* xml, int kind, const char* base, crt_host_scene** out)
+{
+    if (!xml || !out) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    *out = nullptr;
+    if (kind != CRT_SCENE_FILE && kind != CRT_SCENE_TLAS) { g_err = "unknown scene kind"; return CRT_ERR_INVALID; }
+    GUARD_BEGIN
+    crt_host_scene* h = new crt_host_scene();
+    try {
+        const std::string b = base ? base : "";
+        if (kind == CRT_SCENE_FILE) { h->file = new FileScene(xml, b); h->scene = h->file; }
+        else { h->tlas = new TLASFileScene(xml, b); h->scene = h->tlas; }
+    } catch (...) { delete h; throw; }
+    *out = h;
+    return CRT_OK;
+    GUARD_END(CRT_ERR_IO)
+}
+void crt_host_scene_free(crt_host_scene* s) { if (s) { delete s->scene; delete s; } }
+int crt_host_scene_upload(crt_host_scene* s, crt_ctx* ctx)
+{
+    if (!s || !ctx) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    GUARD_BEGIN
+    const int rc = s->scene->Upload(ctx);
+    if (rc != CRT_OK) g_err = crt_last_error(ctx);
+    return rc;
+    GUARD_END(CRT_ERR_INVALID)
+}
+int crt_host_scene_kind(crt_host_scene* s) { return s ? s->scene->Kind() : CRT_ERR_INVALID; }
+int crt_host_scene_triangle_count(crt_host_scene* s) { return s ? s->scene->GetTriangleCount() : CRT_ERR_INVALID; }
+int crt_host_scene_bvh_count(crt_host_scene* s) { return !s ? CRT_ERR_INVALID : (s->file ? 1 : (int)s->tlas->tlas.blas.size()); }
+
+static bool pick(crt_host_scene* s, int i, const std::vector<BVHNode>** nodes, const std::vector<Tri>** tris, const std::vector<uint32_t>** idx, uint32_t* used, uint32_t* depth)
+{
+    if (!s) return false;
+    if (s->file) { if (i != 0) return false; *nodes = &s->file->acc.bvhNodes; *tris = &s->file->acc.triangles; *idx = &s->file->acc.triangleIndices; *used = s->file->acc.nodesUsed; *depth = s->file->acc.maxDepth; return true; }
+    if (i < 0 || i >= (int)s->tlas->tlas.blas.size()) return false;
+    const BLASBVH* b = s->tlas->tlas.blas[(size_t)i];
+    *nodes = &b->bvhNodes; *tris = &b->triangles; *idx = &b->triangleIndices; *used = b->nodesUsed; *depth = b->maxDepth; return true;
+}
+int crt_host_scene_bvh_info(crt_host_scene* s, int i, uint32_t* nodesUsed, uint32_t* triCount, uint32_t* maxDepth)
+{
+    const std::vector<BVHNode>* n; const std::vector<Tri>* t; const std::vector<uint32_t>* x; uint32_t u, d;
+    if (!pick(s, i, &n, &t, &x, &u, &d)) { g_err = "bvh index out of range"; return CRT_ERR_INVALID; }
+    if (nodesUsed) *nodesUsed = u; if (triCount) *triCount = (uint32_t)t->size(); if (maxDepth) *maxDepth = d;
+    return CRT_OK;
+}
+int crt_host_scene_bvh_copy(crt_host_scene* s, int i, crt_bvh_node* nodes, uint32_t* idx, crt_tri* tris)
+{
+    const std::vector<BVHNode>* n; const std::vector<Tri>* t; const std::vector<uint32_t>* x; uint32_t u, d;
+    if (!pick(s, i, &n, &t, &x, &u, &d)) { g_err = "bvh index out of range"; return CRT_ERR_INVALID; }
+    if (nodes) memcpy(nodes, n->data(), sizeof(BVHNode) * u);
+    if (idx) memcpy(idx, x->data(), 4 * x->size());
+    if (tris) memcpy(tris, t->data(), sizeof(Tri) * t->size());
+    return CRT_OK;
+}
+int crt_host_scene_blas_transform(crt_host_scene* s, int i, float T[16], float invT[16], float lo[3], float hi[3])
+{
+    if (!s || !s->tlas || i < 0 || i >= (int)s->tlas->tlas.blas.size()) { g_err = "not a TLAS scene / index out of range"; return CRT_ERR_INVALID; }
+    const BLASBVH* b = s->tlas->tlas.blas[(size_t)i];
+    memcpy(T, b->T.cell, 64); memcpy(invT, b->invT.cell, 64);
+    lo[0] = b->worldBounds.bmin3.x; lo[1] = b->worldBounds.bmin3.y; lo[2] = b->worldBounds.bmin3.z;
+    hi[0] = b->worldBounds.bmax3.x; hi[1] = b->worldBounds.bmax3.y; hi[2] = b->worldBounds.bmax3.z;
+    return CRT_OK;
+}
+int crt_host_scene_tlas_copy(crt_host_scene* s, crt_tlas_node* nodes, uint32_t* nodesUsed)
+{
+    if (!s || !s->tlas) { g_err = "not a TLAS scene"; return CRT_ERR_INVALID; }
+    if (nodes) memcpy(nodes, s->tlas->tlas.tlasNode.data(), sizeof(TLASBVHNode) * s->tlas->tlas.tlasNode.size());
+    if (nodesUsed) *nodesUsed = s->tlas->tlas.nodesUsed;
+    return CRT_OK;
+}
+
+int crt_host_camera_state(int w, int h, const float p[3], const float t[3], float camPos[3], float tl[3], float tr[3], float bl[3])
+{
+    if (w <= 0 || h <= 0 || !p || !t) { g_err = "bad argument"; return CRT_ERR_INVALID; }
+    Camera c(w, h);
+    c.SetCameraState(float3(p[0], p[1], p[2]), float3(t[0], t[1], t[2]));
+    camPos[0] = c.camPos.x; camPos[1] = c.camPos.y; camPos[2] = c.camPos.z;
+    tl[0] = c.topLeft.x; tl[1] = c.topLeft.y; tl[2] = c.topLeft.z;
+    tr[0] = c.topRight.x; tr[1] = c.topRight.y; tr[2] = c.topRight.z;
+    bl[0] = c.bottomLeft.x; bl[1] = c.bottomLeft.y; bl[2] = c.bottomLeft.z;
+    return CRT_OK;
+}
+
+int crt_host_renderer_create(crt_host_scene* s, int w, int h, int device, crt_host_renderer** out)
+{
+    if (!s || !out || w < 16 || h < 16) { g_err = "bad argument"; return CRT_ERR_INVALID; }
+    GUARD_BEGIN
+    crt_host_renderer* r = new crt_host_renderer();
+    r->r = new Renderer(s->scene, w, h, device);
+    *out = r;
+    return CRT_OK;
+    GUARD_END(CRT_ERR_INVALID)
+}
+void crt_host_renderer_destroy(crt_host_renderer* r) { if (r) { delete r->r; delete r; } }
+int crt_host_renderer_init(crt_host_renderer* r) { if (!r) return CRT_ERR_INVALID; GUARD_BEGIN r->r->Init(); return CRT_OK; GUARD_END(CRT_ERR_DEVICE) }
+int crt_host_renderer_set_camera(crt_host_renderer* r, const float p[3], const float t[3])
+{
+    if (!r || !p || !t) return CRT_ERR_INVALID;
+    r->r->camera.SetCameraState(float3(p[0], p[1], p[2]), float3(t[0], t[1], t[2]));
+    return CRT_OK;
+}
+int crt_host_renderer_set_passes(crt_host_renderer* r, int passes) { if (!r || passes < 1 || passes > 4) { g_err = "passes must be 1..4"; return CRT_ERR_INVALID; } r->r->passes = passes; return CRT_OK; }
+int crt_host_renderer_clear(crt_host_renderer* r) { if (!r) return CRT_ERR_INVALID; GUARD_BEGIN r->r->ClearAccumulator(); return CRT_OK; GUARD_END(CRT_ERR_DEVICE) }
+int crt_host_renderer_tick(crt_host_renderer* r, float dt) { if (!r) return CRT_ERR_INVALID; GUARD_BEGIN r->r->Tick(dt); return CRT_OK; GUARD_END(CRT_ERR_DEVICE) }
+int crt_host_renderer_render(crt_host_renderer* r, int frames) { if (!r) return CRT_ERR_INVALID; GUARD_BEGIN r->r->Render(frames); return CRT_OK; GUARD_END(CRT_ERR_DEVICE) }
+int crt_host_renderer_spp(crt_host_renderer* r) { return r ? r->r->spp : CRT_ERR_INVALID; }
+float crt_host_renderer_energy(crt_host_renderer* r) { return r ? r->r->energy : 0.0f; }
+const float* crt_host_renderer_accumulator(crt_host_renderer* r) { return r ? r->r->accumulator : nullptr; }
+const uint32_t* crt_host_renderer_screen(crt_host_renderer* r) { return (r && r->r->screen) ? r->r->screen->pixels.data() : nullptr; }
+crt_ctx* crt_host_renderer_ctx(crt_host_renderer* r) { return r ? r->r->ctx : nullptr; }
+
+int crt_host_obj_load(const char* path, uint32_t* corners, float** pos, float** nrm, float** uv)
+{
+    if (!path || !corners || !pos || !nrm || !uv) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    GUARD_BEGIN
+    const MeshCorners m = LoadObj(path);
+    const size_t n = m.count();
+    *corners = (uint32_t)n;
+    *pos = (float*)malloc(n * 12); *nrm = (float*)malloc(n * 12); *uv = (float*)malloc(n * 8);
+    memcpy(*pos, m.pos.data(), n * 12); memcpy(*nrm, m.nrm.data(), n * 12); memcpy(*uv, m.uv.data(), n * 8);
+    return CRT_OK;
+    GUARD_END(CRT_ERR_IO)
+}
+int crt_host_image_load(const char* path, int* w, int* h, uint32_t** pixels)
+{
+    if (!path || !w || !h || !pixels) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    GUARD_BEGIN
+    const Image img = LoadImage(path);
+    *w = img.width; *h = img.height;
+    *pixels = (uint32_t*)malloc(img.pixels.size() * 4);
+    memcpy(*pixels, img.pixels.data(), img.pixels.size() * 4);
+    return CRT_OK;
+    GUARD_END(CRT_ERR_IO)
+}
+void crt_host_free(void* p) { free(p); }
+
+} // extern "C"

@@ -1,0 +1,493 @@
+// loaders.cpp — OBJ / scene-XML / texture readers of the host front (see loaders.h).
+#include "loaders.h"
+
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+
+namespace crt {
+
+namespace {
+
+[[noreturn]] void fail(const std::string& msg) { throw std::runtime_error(msg); }
+
+std::string readFile(const std::string& path, bool binary)
+{
+    std::ifstream f(path.c_str(), binary ? std::ios::binary : std::ios::in);
+    if (!f) fail("File not found: " + path);
+    std::stringstream ss; ss << f.rdbuf();
+    return ss.str();
+}
+
+// ------------------------------------------------------------------------------------------------
+// OBJ
+// ------------------------------------------------------------------------------------------------
+inline bool isDigit(char c) { return c >= '0' && c <= '9'; }
+
+// decimal -> double with the digit-accumulation scheme of tinyobjloader (lib/tiny_obj_loader.h:891-1021): the value
+// is then narrowed to float, so meshes get the same vertex bits as the reference's loader
+bool parseNumber(const char* s, const char* end, double* out)
+{
+    if (s >= end) return false;
+    double mant = 0.0; int exponent = 0; char sign = '+', esign = '+';
+    const char* c = s; int read = 0; bool leadingDot = false;
+    if (*c == '+' || *c == '-') { sign = *c; c++; if (c != end && *c == '.') leadingDot = true; }
+    else if (isDigit(*c)) {}
+    else if (*c == '.') leadingDot = true;
+    else return false;
+    bool more = (c != end);
+    if (!leadingDot) {
+        while (more && isDigit(*c)) { mant *= 10; mant += (int)(*c - '0'); c++; read++; more = (c != end); }
+        if (read == 0) return false;
+    }
+    if (more) {
+        bool expPart = false;
+        if (*c == '.') {
+            c++; read = 1; more = (c != end);
+            static const double lut[] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+            while (more && isDigit(*c)) {
+                mant += (int)(*c - '0') * (read < 8 ? lut[read] : std::pow(10.0, -read));
+                read++; c++; more = (c != end);
+            }
+            expPart = more && (*c == 'e' || *c == 'E');
+        } else if (*c == 'e' || *c == 'E') expPart = true;
+        if (expPart) {
+            c++; more = (c != end);
+            if (more && (*c == '+' || *c == '-')) { esign = *c; c++; }
+            else if (more && isDigit(*c)) {}
+            else return false;
+            read = 0; more = (c != end);
+            while (more && isDigit(*c)) {
+                if (exponent > 2147483647 / 10) return false;
+                exponent = exponent * 10 + (int)(*c - '0'); c++; read++; more = (c != end);
+            }
+            exponent *= (esign == '+' ? 1 : -1);
+            if (read == 0) return false;
+        }
+    }
+    *out = (sign == '+' ? 1 : -1) * (exponent ? std::ldexp(mant * std::pow(5.0, exponent), exponent) : mant);
+    return true;
+}
+
+float nextReal(const char*& p, double dflt = 0.0)
+{
+    p += strspn(p, " \t");
+    const char* end = p + strcspn(p, " \t\r");
+    double v = dflt;
+    parseNumber(p, end, &v);
+    p = end;
+    return (float)v;
+}
+
+struct Corner { int v = -1, vt = -1, vn = -1; };
+
+bool fixIndex(int idx, int n, int* out)   // lib/tiny_obj_loader.h fixIndex: 1-based, negative = relative, 0 invalid
+{
+    if (idx > 0) { *out = idx - 1; return true; }
+    if (idx == 0) return false;
+    *out = n + idx; return *out >= 0;
+}
+
+bool parseCorner(const char*& p, int nv, int nvn, int nvt, Corner* c)
+{
+    Corner r;
+    if (!fixIndex(atoi(p), nv, &r.v)) return false;
+    p += strcspn(p, "/ \t\r");
+    if (*p != '/') { *c = r; return true; }
+    p++;
+    if (*p == '/') {                       // i//k
+        p++;
+        if (!fixIndex(atoi(p), nvn, &r.vn)) return false;
+        p += strcspn(p, "/ \t\r");
+        *c = r; return true;
+    }
+    if (!fixIndex(atoi(p), nvt, &r.vt)) return false;      // i/j or i/j/k
+    p += strcspn(p, "/ \t\r");
+    if (*p != '/') { *c = r; return true; }
+    p++;
+    if (!fixIndex(atoi(p), nvn, &r.vn)) return false;
+    p += strcspn(p, "/ \t\r");
+    *c = r; return true;
+}
+
+// even-odd point-in-triangle test on the projected coordinates (lib/tiny_obj_loader.h:1413-1423)
+bool insideTri(const float* vx, const float* vy, float tx, float ty)
+{
+    bool c = false;
+    for (int i = 0, j = 2; i < 3; j = i++)
+        if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) c = !c;
+    return c;
+}
+
+} // namespace
+
+MeshCorners LoadObj(const std::string& path)
+{
+    const std::string text = readFile(path, false);
+    std::vector<float> V, VN, VT;
+    std::vector<Corner> out;           // three per triangle
+    size_t pos = 0; int lineNo = 0;
+    auto emit = [&](const Corner& a, const Corner& b, const Corner& c) { out.push_back(a); out.push_back(b); out.push_back(c); };
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        std::string line = text.substr(pos, eol - pos);
+        pos = eol + 1; lineNo++;
+        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+        const char* p = line.c_str();
+        p += strspn(p, " \t");
+        if (*p == '\0' || *p == '#') continue;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) { p += 2; float x = nextReal(p), y = nextReal(p), z = nextReal(p); V.push_back(x); V.push_back(y); V.push_back(z); continue; }
+        if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) { p += 3; float x = nextReal(p), y = nextReal(p), z = nextReal(p); VN.push_back(x); VN.push_back(y); VN.push_back(z); continue; }
+        if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t')) { p += 3; float x = nextReal(p), y = nextReal(p); VT.push_back(x); VT.push_back(y); continue; }
+        if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            p += 2; p += strspn(p, " \t");
+            std::vector<Corner> face;
+            while (*p != '\0' && *p != '\r' && *p != '\n') {
+                Corner c;
+                if (!parseCorner(p, (int)(V.size() / 3), (int)(VN.size() / 3), (int)(VT.size() / 2), &c))
+                    fail(path + ":" + std::to_string(lineNo) + ": failed to parse `f' line (invalid vertex index)");
+                face.push_back(c);
+                p += strspn(p, " \t\r");
+            }
+            const size_t n = face.size();
+            if (n < 3) continue;                                    // degenerate face, dropped as tinyobj does
+            for (const Corner& c : face)
+                if (c.v < 0 || (size_t)c.v * 3 + 2 >= V.size() || (c.vn >= 0 && (size_t)c.vn * 3 + 2 >= VN.size()) || (c.vt >= 0 && (size_t)c.vt * 2 + 1 >= VT.size()))
+                    fail(path + ":" + std::to_string(lineNo) + ": face references a vertex / normal / texcoord that does not exist");
+            if (n == 3) { emit(face[0], face[1], face[2]); continue; }
+            if (n == 4) {                                           // shorter diagonal, strict <  (tiny_obj_loader.h:1488-1588)
+                const float* p0 = &V[3 * face[0].v]; const float* p1 = &V[3 * face[1].v]; const float* p2 = &V[3 * face[2].v]; const float* p3 = &V[3 * face[3].v];
+                const float ax = p2[0] - p0[0], ay = p2[1] - p0[1], az = p2[2] - p0[2];
+                const float bx = p3[0] - p1[0], by = p3[1] - p1[1], bz = p3[2] - p1[2];
+                const float d02 = ax * ax + ay * ay + az * az, d13 = bx * bx + by * by + bz * bz;
+                if (d02 < d13) { emit(face[0], face[1], face[2]); emit(face[0], face[2], face[3]); }
+                else { emit(face[0], face[1], face[3]); emit(face[1], face[2], face[3]); }
+                continue;
+            }
+            // n > 4: ear clipping in the plane of the two dominant axes (tiny_obj_loader.h:1714-1935)
+            size_t axes[2] = {1, 2};
+            for (size_t k = 0; k < n; ++k) {
+                const float* a = &V[3 * face[(k + 0) % n].v]; const float* b = &V[3 * face[(k + 1) % n].v]; const float* c = &V[3 * face[(k + 2) % n].v];
+                const float e0x = b[0] - a[0], e0y = b[1] - a[1], e0z = b[2] - a[2];
+                const float e1x = c[0] - b[0], e1y = c[1] - b[1], e1z = c[2] - b[2];
+                const float cx = std::fabs(e0y * e1z - e0z * e1y), cy = std::fabs(e0z * e1x - e0x * e1z), cz = std::fabs(e0x * e1y - e0y * e1x);
+                const float eps = std::numeric_limits<float>::epsilon();
+                if (cx > eps || cy > eps || cz > eps) {
+                    if (!(cx > cy && cx > cz)) { axes[0] = 0; if (cz > cx && cz > cy) axes[1] = 1; }
+                    break;
+                }
+            }
+            std::vector<Corner> rest = face;
+            size_t guess = 0, budget = face.size(), prevSize = rest.size();
+            while (rest.size() > 3 && budget > 0) {
+                const size_t m = rest.size();
+                if (guess >= m) guess -= m;
+                if (prevSize != m) { prevSize = m; budget = m; } else budget--;
+                Corner ind[3]; float vx[3], vy[3];
+                for (size_t k = 0; k < 3; k++) { ind[k] = rest[(guess + k) % m]; vx[k] = V[3 * ind[k].v + axes[0]]; vy[k] = V[3 * ind[k].v + axes[1]]; }
+                const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+                const float crs = e0x * e1y - e0y * e1x;
+                const float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+                if (crs * area < 0.0f) { guess += 1; continue; }
+                bool overlap = false;
+                for (size_t other = 3; other < m; ++other) {
+                    const size_t oi = (guess + other) % m;
+                    const float tx = V[3 * rest[oi].v + axes[0]], ty = V[3 * rest[oi].v + axes[1]];
+                    if (insideTri(vx, vy, tx, ty)) { overlap = true; break; }
+                }
+                if (overlap) { guess += 1; continue; }
+                emit(ind[0], ind[1], ind[2]);
+                rest.erase(rest.begin() + (long)((guess + 1) % m));
+            }
+            if (rest.size() == 3) emit(rest[0], rest[1], rest[2]);
+            continue;
+        }
+        // o, g, s, usemtl, mtllib, l, p, ...: no effect on the triangle list the path tracer consumes
+    }
+    MeshCorners m;
+    m.pos.resize(out.size() * 3, 0.0f); m.nrm.resize(out.size() * 3, 0.0f); m.uv.resize(out.size() * 2, 0.0f);
+    for (size_t i = 0; i < out.size(); i++) {
+        const Corner& c = out[i];
+        memcpy(&m.pos[3 * i], &V[3 * c.v], 12);
+        if (c.vn >= 0) memcpy(&m.nrm[3 * i], &VN[3 * c.vn], 12);
+        if (c.vt >= 0) memcpy(&m.uv[2 * i], &VT[2 * c.vt], 8);
+    }
+    if (out.empty()) fail(path + ": no faces");
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// images
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Raw { int w = 0, h = 0, n = 0; std::vector<uint8_t> px; };   // n interleaved 8-bit channels, top row first
+
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+Raw decodePng(const std::string& d, const std::string& path)
+{
+    const uint8_t* p = (const uint8_t*)d.data(); const size_t size = d.size();
+    size_t o = 8; uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0; bool haveHdr = false;
+    std::vector<uint8_t> idat, plte, trns;
+    while (o + 8 <= size) {
+        const uint32_t len = be32(p + o); const std::string typ((const char*)p + o + 4, 4);
+        if (o + 12 + (size_t)len > size) fail(path + ": truncated PNG chunk");
+        const uint8_t* body = p + o + 8;
+        if (typ == "IHDR") { w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; haveHdr = true; }
+        else if (typ == "IDAT") idat.insert(idat.end(), body, body + len);
+        else if (typ == "PLTE") plte.assign(body, body + len);
+        else if (typ == "tRNS") trns.assign(body, body + len);
+        else if (typ == "IEND") break;
+        o += 12 + (size_t)len;
+    }
+    if (!haveHdr || w == 0 || h == 0) fail(path + ": bad PNG header");
+    if (interlace) fail(path + ": interlaced PNG is not supported by this loader");
+    int ch; switch (ctype) { case 0: ch = 1; break; case 2: ch = 3; break; case 3: ch = 1; break; case 4: ch = 2; break; case 6: ch = 4; break; default: fail(path + ": bad PNG colour type"); }
+    if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) fail(path + ": unsupported PNG bit depth");
+    const size_t bpp = (size_t)ch * depth;                         // bits per pixel
+    const size_t stride = ((size_t)w * bpp + 7) / 8, fb = (bpp + 7) / 8;  // filter byte distance
+    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    uLongf dl = (uLongf)raw.size();
+    if (uncompress(raw.data(), &dl, idat.data(), (uLong)idat.size()) != Z_OK || dl != raw.size()) fail(path + ": PNG inflate failed");
+    std::vector<uint8_t> img(stride * (size_t)h);
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t ft = raw[(stride + 1) * y]; const uint8_t* in = &raw[(stride + 1) * y + 1];
+        uint8_t* cur = &img[stride * y]; const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+        for (size_t x = 0; x < stride; x++) {
+            const int a = x >= fb ? cur[x - fb] : 0, b = up ? up[x] : 0, c = (up && x >= fb) ? up[x - fb] : 0;
+            int pr = 0;
+            switch (ft) {
+                case 0: pr = 0; break; case 1: pr = a; break; case 2: pr = b; break; case 3: pr = (a + b) >> 1; break;
+                case 4: { const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c); pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                default: fail(path + ": bad PNG filter");
+            }
+            cur[x] = (uint8_t)(in[x] + pr);
+        }
+    }
+    // to 8-bit samples (16-bit keeps the high byte; sub-byte grey is scaled, palette indices stay) — as stb_image does
+    std::vector<uint8_t> s8((size_t)w * h * ch);
+    for (uint32_t y = 0; y < h; y++) for (size_t i = 0; i < (size_t)w * ch; i++) {
+        uint8_t v;
+        const uint8_t* row = &img[stride * y];
+        if (depth == 8) v = row[i];
+        else if (depth == 16) v = row[2 * i];
+        else { const int per = 8 / depth; const int sh = (per - 1 - (int)(i % per)) * depth; v = (uint8_t)((row[i / per] >> sh) & ((1 << depth) - 1)); if (ctype == 0) v = (uint8_t)(v * (255 / ((1 << depth) - 1))); }
+        s8[(size_t)y * w * ch + i] = v;
+    }
+    Raw r; r.w = (int)w; r.h = (int)h;
+    if (ctype == 3) {
+        r.n = trns.empty() ? 3 : 4; r.px.resize((size_t)w * h * r.n);
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            const size_t k = s8[i];
+            if (k * 3 + 2 >= plte.size()) fail(path + ": palette index out of range");
+            r.px[i * r.n] = plte[k * 3]; r.px[i * r.n + 1] = plte[k * 3 + 1]; r.px[i * r.n + 2] = plte[k * 3 + 2];
+            if (r.n == 4) r.px[i * 4 + 3] = k < trns.size() ? trns[k] : 255;
+        }
+    } else if (!trns.empty() && (ctype == 0 || ctype == 2)) {   // colour-key transparency adds an alpha channel
+        r.n = ch + 1; r.px.resize((size_t)w * h * r.n);
+        for (size_t i = 0; i < (size_t)w * h; i++) { for (int k = 0; k < ch; k++) r.px[i * r.n + k] = s8[i * ch + k]; r.px[i * r.n + ch] = 255; }
+    } else { r.n = ch; r.px.swap(s8); }
+    return r;
+}
+
+Raw decodeTga(const std::string& d, const std::string& path)
+{
+    const uint8_t* p = (const uint8_t*)d.data();
+    if (d.size() < 18) fail(path + ": truncated TGA");
+    const int idlen = p[0], cmap = p[1], typ = p[2], w = p[12] | (p[13] << 8), h = p[14] | (p[15] << 8), bpp = p[16], desc = p[17];
+    const bool rle = typ >= 8; const int base = typ & 7;
+    if (cmap != 0 || !(base == 2 || base == 3) || !((base == 2 && (bpp == 24 || bpp == 32)) || (base == 3 && bpp == 8)))
+        fail(path + ": unsupported TGA variant (only 8-bit grey and 24/32-bit true colour, raw or RLE)");
+    const int n = bpp / 8; size_t o = 18 + (size_t)idlen;
+    std::vector<uint8_t> px((size_t)w * h * n);
+    if (!rle) { if (o + px.size() > d.size()) fail(path + ": truncated TGA"); memcpy(px.data(), p + o, px.size()); }
+    else {
+        size_t i = 0;
+        while (i < px.size()) {
+            if (o >= d.size()) fail(path + ": truncated TGA");
+            const int c = p[o++]; const size_t cnt = (size_t)(c & 127) + 1;
+            if (c & 128) { if (o + n > d.size()) fail(path + ": truncated TGA"); for (size_t k = 0; k < cnt && i < px.size(); k++, i += n) memcpy(&px[i], p + o, n); o += n; }
+            else { const size_t bytes = cnt * n; if (o + bytes > d.size() || i + bytes > px.size()) fail(path + ": truncated TGA"); memcpy(&px[i], p + o, bytes); o += bytes; i += bytes; }
+        }
+    }
+    Raw r; r.w = w; r.h = h; r.n = n; r.px.resize(px.size());
+    const bool topDown = (desc & 0x20) != 0;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* src = &px[(size_t)(topDown ? y : h - 1 - y) * w * n]; uint8_t* dst = &r.px[(size_t)y * w * n];
+        for (int x = 0; x < w; x++) {
+            if (n >= 3) { dst[x * n] = src[x * n + 2]; dst[x * n + 1] = src[x * n + 1]; dst[x * n + 2] = src[x * n]; if (n == 4) dst[x * n + 3] = src[x * n + 3]; }
+            else dst[x] = src[x];
+        }
+    }
+    return r;
+}
+
+Raw decodePnm(const std::string& d, const std::string& path)
+{
+    size_t o = 2; int vals[3], got = 0;
+    while (got < 3 && o < d.size()) {
+        while (o < d.size() && (d[o] == ' ' || d[o] == '\n' || d[o] == '\r' || d[o] == '\t')) o++;
+        if (o < d.size() && d[o] == '#') { while (o < d.size() && d[o] != '\n') o++; continue; }
+        int v = 0; bool any = false; while (o < d.size() && isDigit(d[o])) { v = v * 10 + (d[o] - '0'); o++; any = true; }
+        if (!any) fail(path + ": bad PNM header");
+        vals[got++] = v;
+    }
+    o++;    // single whitespace after maxval
+    Raw r; r.w = vals[0]; r.h = vals[1]; r.n = d[1] == '6' ? 3 : 1;
+    if (vals[2] != 255 || o + (size_t)r.w * r.h * r.n > d.size()) fail(path + ": unsupported / truncated PNM");
+    r.px.assign((const uint8_t*)d.data() + o, (const uint8_t*)d.data() + o + (size_t)r.w * r.h * r.n);
+    return r;
+}
+
+} // namespace
+
+Image LoadImage(const std::string& path)
+{
+    const std::string d = readFile(path, true);
+    Raw r;
+    if (d.size() >= 8 && memcmp(d.data(), "\x89PNG\r\n\x1a\n", 8) == 0) r = decodePng(d, path);
+    else if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) r = decodePnm(d, path);
+    else if (d.size() >= 3 && (uint8_t)d[0] == 0xFF && (uint8_t)d[1] == 0xD8) fail(path + ": JPEG textures are not supported by this loader yet (convert to PNG)");
+    else r = decodeTga(d, path);
+    Image img; img.width = r.w; img.height = r.h; img.pixels.resize((size_t)r.w * r.h);
+    const size_t s = (size_t)r.w * r.h;
+    if (r.n == 1) for (size_t i = 0; i < s; i++) { const uint32_t p = r.px[i]; img.pixels[i] = p + (p << 8) + (p << 16); }      // texture.h:25-31
+    else for (size_t i = 0; i < s; i++) {                                                                                          // texture.h:33-36
+        const size_t b = i * r.n;
+        const uint32_t c2 = (b + 2 < r.px.size()) ? r.px[b + 2] : 0u;      // n == 2 reads one byte past the pixel in the reference
+        img.pixels[i] = ((uint32_t)r.px[b] << 16) + ((uint32_t)r.px[b + 1] << 8) + c2;
+    }
+    return img;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene XML
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct XNode { std::string name, text; std::vector<XNode> kids; const XNode* child(const char* n) const { for (auto& k : kids) if (k.name == n) return &k; return nullptr; } };
+
+struct XParser {
+    const std::string& s; size_t i = 0; const std::string& path;
+    [[noreturn]] void err(const char* what) { fail(path + ": XML parse error: " + what); }
+    void skipMisc()
+    {
+        for (;;) {
+            while (i < s.size() && isspace((unsigned char)s[i])) i++;
+            if (s.compare(i, 4, "<!--") == 0) { size_t e = s.find("-->", i + 4); if (e == std::string::npos) err("unterminated comment"); i = e + 3; }
+            else if (s.compare(i, 2, "<?") == 0) { size_t e = s.find("?>", i + 2); if (e == std::string::npos) err("unterminated declaration"); i = e + 2; }
+            else if (s.compare(i, 2, "<!") == 0) { size_t e = s.find('>', i); if (e == std::string::npos) err("unterminated doctype"); i = e + 1; }
+            else return;
+        }
+    }
+    static void decode(std::string& t)
+    {
+        static const struct { const char* e; char c; } ent[] = {{"&amp;", '&'}, {"&lt;", '<'}, {"&gt;", '>'}, {"&quot;", '"'}, {"&apos;", '\''}};
+        for (auto& en : ent) { size_t p = 0; const size_t l = strlen(en.e); while ((p = t.find(en.e, p)) != std::string::npos) { t.replace(p, l, 1, en.c); p++; } }
+    }
+    XNode element()
+    {
+        if (i >= s.size() || s[i] != '<') err("expected element");
+        i++;
+        XNode n; size_t b = i;
+        while (i < s.size() && !isspace((unsigned char)s[i]) && s[i] != '>' && s[i] != '/') i++;
+        n.name = s.substr(b, i - b);
+        if (n.name.empty()) err("empty element name");
+        // attributes are not used by the scene schema: skip to the end of the tag
+        while (i < s.size() && s[i] != '>') { if (s[i] == '"' || s[i] == '\'') { const char q = s[i++]; while (i < s.size() && s[i] != q) i++; } if (s[i] == '/' && i + 1 < s.size() && s[i + 1] == '>') { i += 2; return n; } i++; }
+        if (i >= s.size()) err("unterminated tag");
+        i++;
+        bool firstData = true;
+        for (;;) {
+            const size_t contentStart = i;
+            // whitespace between '>' and '<' is not a data node; text keeps its leading whitespace (rapidxml parse<0>)
+            size_t j = i; while (j < s.size() && isspace((unsigned char)s[j])) j++;
+            if (j >= s.size()) err("unexpected end of file");
+            if (s[j] == '<') {
+                i = j;
+                if (s.compare(i, 2, "</") == 0) { size_t e = s.find('>', i); if (e == std::string::npos) err("unterminated end tag"); i = e + 1; return n; }
+                if (s.compare(i, 4, "<!--") == 0) { size_t e = s.find("-->", i + 4); if (e == std::string::npos) err("unterminated comment"); i = e + 3; continue; }
+                if (s.compare(i, 9, "<![CDATA[") == 0) { size_t e = s.find("]]>", i + 9); if (e == std::string::npos) err("unterminated CDATA"); if (firstData) { n.text = s.substr(i + 9, e - i - 9); firstData = false; } i = e + 3; continue; }
+                n.kids.push_back(element());
+            } else {
+                size_t e = s.find('<', j); if (e == std::string::npos) err("unexpected end of file");
+                if (firstData) { n.text = s.substr(contentStart, e - contentStart); decode(n.text); firstData = false; }
+                i = e;
+            }
+        }
+    }
+};
+
+float toFloat(const XNode* n, const std::string& path, const char* what)
+{
+    if (!n) fail(path + ": missing <" + what + ">");
+    try { return std::stof(n->text); } catch (...) { fail(path + ": <" + what + "> is not a number"); }
+}
+float3 toXYZ(const XNode* n, const std::string& path, const char* what)
+{
+    if (!n) fail(path + ": missing <" + what + ">");
+    float3 v(0, 0, 0);
+    for (const XNode& k : n->kids) {
+        const int idx = k.name[0] - 'x';                      // 'x','y','z' -> 0,1,2 (file_scene.cpp:82)
+        if (idx < 0 || idx > 2) fail(path + ": <" + what + "> has a child that is not x / y / z");
+        try { v[idx] = std::stof(k.text); } catch (...) { fail(path + ": <" + what + "> component is not a number"); }
+    }
+    return v;
+}
+const std::string& toText(const XNode* n, const std::string& path, const char* what)
+{
+    if (!n) fail(path + ": missing <" + what + ">");
+    return n->text;
+}
+
+} // namespace
+
+SceneData LoadSceneFile(const std::string& path)
+{
+    const std::string text = readFile(path, false);
+    XParser xp{text, 0, path};
+    xp.skipMisc();
+    XNode root = xp.element();
+    if (root.name != "scene") fail(path + ": root element must be <scene>");
+    SceneData sd;
+    sd.name = toText(root.child("scene_name"), path, "scene_name");
+    sd.lightPos = toXYZ(root.child("light_position"), path, "light_position");
+    sd.planeTextureLocation = toText(root.child("plane_texture_location"), path, "plane_texture_location");
+    sd.skydomeLocation = toText(root.child("skydome_location"), path, "skydome_location");
+    const XNode* objs = root.child("objects");
+    if (!objs) fail(path + ": missing <objects>");
+    bool started = false;
+    for (const XNode& o : objs->kids) {
+        if (!started) { if (o.name != "object") continue; started = true; }    // first_node("object"), then every next_sibling()
+        ObjectData od;
+        od.modelLocation = toText(o.child("model_location"), path, "model_location");
+        try { od.materialIdx = std::stoi(toText(o.child("material_idx"), path, "material_idx")); } catch (const std::runtime_error&) { throw; } catch (...) { fail(path + ": <material_idx> is not an integer"); }
+        od.position = toXYZ(o.child("position"), path, "position");
+        od.rotation = toXYZ(o.child("rotation"), path, "rotation");
+        od.scale = toXYZ(o.child("scale"), path, "scale");
+        sd.objects.push_back(od);
+    }
+    const XNode* mats = root.child("materials");
+    if (!mats) fail(path + ": missing <materials>");
+    started = false;
+    for (const XNode& m : mats->kids) {
+        if (!started) { if (m.name != "material") continue; started = true; }
+        MaterialData md;
+        md.reflectivity = toFloat(m.child("reflectivity"), path, "reflectivity");
+        md.refractivity = toFloat(m.child("refractivity"), path, "refractivity");
+        md.absorption = toXYZ(m.child("absorption"), path, "absorption");
+        md.textureLocation = toText(m.child("texture_location"), path, "texture_location");
+        sd.materials.push_back(md);
+    }
+    return sd;
+}
+
+} // namespace crt

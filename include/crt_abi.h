@@ -1,0 +1,171 @@
+/*
+ * crt_abi.h — C ABI of the MI355X path-tracing back end (libcrt_amd.so).
+ *
+ * The reference (willake/cpu-ray-tracer) has no plugin/FFI seam: the path tracer is compiled into the
+ * application.  The two seams it does have are
+ *     upper:  TheApp::Init / Tick(float) and the public Renderer members (accumulator, spp, passes, energy, …)
+ *             — template/precomp.h:344-361, "3. PathTracer/renderer.h":27-53
+ *     lower:  BaseScene::FindNearest / GetHitInfo / GetSkyColor and the public members of the accel classes
+ *             (bvhNodes, triangles, triangleIndices, nodesUsed, T, invT, blas) — infra/scene/base_scene.h:16-32,
+ *             infra/bvh.h:37-43, infra/blas_bvh.h:48-57, infra/tlas_bvh.h:27-31
+ * This header is what a binding behind those seams calls.  The host application keeps loading scenes and
+ * building the SAH-BVH / TLAS on the CPU exactly as today; it hands the BUILT arrays (reference layouts,
+ * borrowed pointers, copied during the call) to crt_upload_scene once, and replaces the body of
+ * Renderer::Tick's tile loop by crt_render.  INTEGRATION.md shows the binding.
+ *
+ * Conventions: every function returns 0 on success or a negative crt_status; no function throws or exits
+ * (the reference's FatalError/exit and std::runtime_error — template/opencl.cpp:14-27, infra/blas_bvh.cpp:11-14 —
+ * become error codes + crt_last_error).  Plain pointers and sizes only; no C++ or torch types.
+ * One host thread drives one ctx; work is asynchronous on the ctx's HIP stream until crt_sync / a read.
+ */
+#ifndef CRT_ABI_H
+#define CRT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_ABI_VERSION 1
+
+typedef enum crt_status {
+    CRT_OK = 0,
+    CRT_ERR_INVALID = -1,      /* bad argument / inconsistent scene description            */
+    CRT_ERR_DEVICE = -2,       /* HIP runtime error (message in crt_last_error)            */
+    CRT_ERR_NO_DEVICE = -3,    /* no gfx950 device visible: the product never falls back to a CPU path */
+    CRT_ERR_UNSUPPORTED = -4,  /* valid input outside this build's limits (stated in the message) */
+    CRT_ERR_STATE = -5,        /* call order (e.g. render before upload)                   */
+    CRT_ERR_IO = -6            /* host loader: file missing / malformed                    */
+} crt_status;
+
+typedef struct crt_ctx crt_ctx;
+
+/* ---- reference record layouts (bit-compatible with the reference structs) ------------------------- */
+
+/* BVHNode — infra/blas_bvh.h:13-20 (32 bytes).  Leaf iff triCount > 0; children at leftFirst, leftFirst+1. */
+typedef struct crt_bvh_node { float aabbMin[3], aabbMax[3]; uint32_t leftFirst, triCount; } crt_bvh_node;
+
+/* Tri — infra/helper.h:6-26 (112 bytes AoS). */
+typedef struct crt_tri {
+    float vertex0[3], vertex1[3], vertex2[3];
+    float normal0[3], normal1[3], normal2[3];
+    float uv0[2], uv1[2], uv2[2];
+    float centroid[3];
+    int32_t objIdx;
+} crt_tri;
+
+/* TLASBVHNode — infra/tlas_bvh.h:7-14 (32 bytes).  Leaf iff leftRight == 0; children = lo/hi 16 bits. */
+typedef struct crt_tlas_node { float aabbMin[3]; uint32_t leftRight; float aabbMax[3]; uint32_t BLAS; } crt_tlas_node;
+
+/* Texture — template/texture.h:15-48: 0x00RRGGBB texels, row 0 = top of the image. */
+typedef struct crt_texture { const uint32_t* pixels; int32_t width, height; } crt_texture;
+
+/* Material — template/material.h:6-46.  texture = index into crt_scene_desc.textures or -1. */
+typedef struct crt_material { float reflectivity, refractivity; float absorption[3]; int32_t texture; } crt_material;
+
+/* One acceleration structure: BVH (infra/bvh.h) for CRT_SCENE_FILE, BLASBVH (infra/blas_bvh.h) for CRT_SCENE_TLAS. */
+typedef struct crt_bvh {
+    const crt_bvh_node* nodes;         /* bvhNodes.data()                                              */
+    uint32_t nodesUsed;                /* nodesUsed (root = 0, node 1.. allocated pairwise)            */
+    const crt_tri* triangles;          /* triangles.data()                                             */
+    uint32_t triCount;                 /* triangles.size()                                             */
+    const uint32_t* triangleIndices;   /* triangleIndices.data()                                       */
+    int32_t objIdx;                    /* BLASBVH::objIdx (hit id written by IntersectTri); ignored for CRT_SCENE_FILE */
+    int32_t matIdx;                    /* BLASBVH::matIdx; ignored for CRT_SCENE_FILE                  */
+    float T[16], invT[16];             /* BLASBVH::T / invT, row-major mat4; ignored for CRT_SCENE_FILE */
+} crt_bvh;
+
+typedef enum crt_scene_kind { CRT_SCENE_FILE = 0 /* FileScene, USE_BVH */, CRT_SCENE_TLAS = 1 /* TLASFileScene, TLAS_USE_BVH */ } crt_scene_kind;
+
+typedef struct crt_scene_desc {
+    int32_t kind;
+    const crt_bvh* bvhs; uint32_t bvhCount;              /* FILE: exactly 1 (FileScene::acc); TLAS: tlas.blas[]            */
+    const crt_tlas_node* tlasNodes; uint32_t tlasNodeCount; /* TLAS only: tlasNode[0 .. 2*blasCount)                         */
+    const int32_t* objMatIdx; uint32_t objCount;         /* FILE only: models[i]->matIdx for object id i+2                 */
+    const crt_material* materials; uint32_t materialCount;
+    const crt_texture* textures; uint32_t textureCount;
+    int32_t floorTexture;                                /* primitiveMaterials[1].textureDiffuse (index into textures)      */
+    int32_t skyTexture;                                  /* skydome                                                          */
+    float lightT[16], lightInvT[16], lightSize;          /* Quad light (template/primitives.h:321-375): T, invT, size       */
+    float floorN[3], floorD, floorInvto;                 /* Plane floor (primitives.h:100-179): N, d, invto                 */
+} crt_scene_desc;
+
+typedef struct crt_config {
+    int32_t width, height;       /* SCRWIDTH / SCRHEIGHT (template/camera.h:4-5)                                      */
+    int32_t depthLimit;          /* Renderer::depthLimit (renderer.h:53), default 5                                   */
+    int32_t device;              /* HIP device ordinal                                                                  */
+    /* image tiles owned by this ctx: tile = tileFirst + i*tileStride, i in [0, tileCount); tileCount < 0 = all.
+     * Tiles are numbered x-major as in Renderer::Tick (renderer.cpp:151-152).  Other pixels are never touched. */
+    int32_t tileFirst, tileStride, tileCount;
+    int32_t maxFramesPerLaunch;  /* 0 = default (64): frames rendered per kernel launch = lanes of one wavefront        */
+    int32_t collectStats;        /* !=0: kernels also count node iterations / triangle tests / BLAS visits / mesh hits   */
+} crt_config;
+
+typedef struct crt_ray { float O[3]; float D[3]; int32_t inside; } crt_ray;
+typedef struct crt_hit {
+    float t; float u, v; int32_t objIdx; int32_t triIdx;
+    int32_t traversed;   /* node iterations, as Ray::traversed (bvh.cpp:231, tlas_bvh.cpp:89)                      */
+    int32_t tested;      /* triangle tests over the whole query                                                     */
+} crt_hit;
+
+typedef struct crt_counters {
+    uint64_t rays;            /* FindNearest calls = primary + secondary rays                                       */
+    uint64_t primary;
+    uint64_t interior_iters;  /* I   (valid when collectStats)                                                      */
+    uint64_t leaf_iters;
+    uint64_t tri_tests;       /* T                                                                                   */
+    uint64_t tlas_iters;
+    uint64_t blas_visits;     /* V                                                                                   */
+    uint64_t mesh_hits;       /* H                                                                                   */
+} crt_counters;
+
+typedef struct crt_timing {
+    float render_kernel_ms;   /* Σ duration of the path-tracing kernel launches of the last crt_render (HIP events on the ctx stream) */
+    float resolve_kernel_ms;  /* Σ duration of the ordered accumulate kernels of the last crt_render                 */
+    uint32_t render_launches; /* number of path-tracing kernel launches in the last crt_render                       */
+    uint32_t reserved;
+} crt_timing;
+
+/* ---- life cycle ----------------------------------------------------------------------------------- */
+int  crt_abi_version(void);
+int  crt_device_count(void);                                   /* number of visible HIP devices (0 = none)          */
+int  crt_create(crt_ctx** out, const crt_config* cfg);
+void crt_destroy(crt_ctx* ctx);
+const char* crt_last_error(crt_ctx* ctx);                      /* ctx may be NULL: error of the last failed crt_create on this thread */
+
+/* ---- scene / camera (lower seam) -------------------------------------------------------------------- */
+int  crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* scene);   /* flattens to the device layout and copies; host pointers are not kept */
+int  crt_set_camera(crt_ctx* ctx, const float camPos[3], const float topLeft[3], const float topRight[3], const float bottomLeft[3]);
+                                                                /* Camera members used by GetPrimaryRay (camera.h:23-30) */
+
+/* ---- rendering (upper seam: the tile loop of Renderer::Tick) --------------------------------------- */
+/* Renders `frames` consecutive Ticks: frame k uses spp = spp_first + k*passes for its tile seeds
+ * (renderer.cpp:120,167) and adds passes samples per pixel into the accumulator in frame order. */
+int  crt_render(crt_ctx* ctx, uint32_t spp_first, uint32_t frames, uint32_t passes);
+int  crt_sync(crt_ctx* ctx);
+int  crt_clear(crt_ctx* ctx);                                   /* Renderer::ClearAccumulator (renderer.cpp:15-18)    */
+int  crt_read_accumulator(crt_ctx* ctx, float* host_rgba /* float4[width*height] */);
+/* screen->pixels and Renderer::energy as ProcessTile/Tick leave them (renderer.cpp:119,127-129,155-157):
+ * pixel = accumulator * scale, scale = 1/(spp+passes) of the LAST rendered frame.  Either output may be NULL. */
+int  crt_resolve_screen(crt_ctx* ctx, float scale, uint32_t* host_pixels /* width*height */, float* energy);
+
+/* ---- query entry = scene.FindNearest(ray) ------------------------------------------------------------ */
+int  crt_find_nearest(crt_ctx* ctx, const crt_ray* rays, crt_hit* hits, size_t n);
+
+/* ---- instrumentation ---------------------------------------------------------------------------------- */
+int  crt_get_counters(crt_ctx* ctx, crt_counters* out);        /* cumulative since create / crt_reset_counters       */
+int  crt_reset_counters(crt_ctx* ctx);
+int  crt_get_timing(crt_ctx* ctx, crt_timing* out);            /* syncs the stream                                   */
+
+/* ---- multi-GPU plumbing ---------------------------------------------------------------------------------
+ * The accumulator can live in caller-owned device memory (e.g. a torch tensor that torch.distributed/RCCL
+ * reduces over xGMI).  Must be width*height*16 bytes, 16-byte aligned, on cfg.device.  NULL = back to internal. */
+int  crt_bind_accumulator(crt_ctx* ctx, void* device_ptr);
+int  crt_accumulator_device_ptr(crt_ctx* ctx, void** device_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -28,6 +28,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -1172,6 +1173,24 @@ int orc_whitted_render(orc_ctx* c, int nThreads)
     if (nThreads == 1) worker(0);
     else { std::vector<std::thread> th; for (int t = 0; t < nThreads; t++) th.emplace_back(worker, t); for (auto& t : th) t.join(); }
     for (auto& cn : cns) c->counters.add(cn);
+    return 0;
+}
+
+// PNG scanline un-filtering for the oracle-side image reader (oracle/orc.py inflates with Python's zlib);
+// raw = h rows of (1 filter byte + stride bytes), fb = bytes per complete pixel.  Independent of the product's decoder.
+int orc_png_unfilter(const uint8_t* raw, uint8_t* out, int stride, int h, int fb)
+{
+    for (int y = 0; y < h; y++) {
+        const uint8_t ft = raw[(size_t)(stride + 1) * y]; const uint8_t* in = raw + (size_t)(stride + 1) * y + 1;
+        uint8_t* cur = out + (size_t)stride * y; const uint8_t* up = y ? out + (size_t)stride * (y - 1) : nullptr;
+        for (int x = 0; x < stride; x++) {
+            int a = x >= fb ? cur[x - fb] : 0, b = up ? up[x] : 0, c = (up && x >= fb) ? up[x - fb] : 0, pr;
+            if (ft == 0) pr = 0; else if (ft == 1) pr = a; else if (ft == 2) pr = b; else if (ft == 3) pr = (a + b) >> 1;
+            else if (ft == 4) { int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            else return -1;
+            cur[x] = (uint8_t)(in[x] + pr);
+        }
+    }
     return 0;
 }
 

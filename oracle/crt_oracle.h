@@ -99,6 +99,9 @@ int orc_sample(orc_ctx*, const orc_ray_in* ray, uint32_t* seed, float rgb[3]);
 /* Whitted integrator (2. WhittedStyle/renderer.cpp) — CPU plumbing for BASELINE config #1 */
 int orc_whitted_render(orc_ctx*, int n_threads);               /* one frame into accumulator (xyz) */
 
+/* helper for the oracle-side PNG reader (oracle/orc.py) */
+int orc_png_unfilter(const uint8_t* raw, uint8_t* out, int stride, int h, int fb);
+
 /* deterministic math used for absorption / skydome lookups (see DESIGN.md "numerics") */
 float orc_expf(float x);
 float orc_atan2f(float y, float x);

@@ -435,35 +435,12 @@ def read_png(path):
             break
     assert depth == 8 and interlace == 0, "unsupported PNG (depth %d, interlace %d)" % (depth, interlace)
     ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
-    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * ch)
-    out = np.zeros((h, w * ch), np.int32)
-    prev = np.zeros(w * ch, np.int32)
-    for y in range(h):
-        ft = raw[y, 0]
-        line = raw[y, 1:].astype(np.int32)
-        if ft == 0:
-            cur = line
-        elif ft == 2:
-            cur = (line + prev) & 255
-        elif ft == 1:
-            cur = line.reshape(w, ch).copy()
-            cur = (np.cumsum(cur, axis=0) & 255).reshape(-1)
-        else:
-            cur = np.zeros(w * ch, np.int32)
-            for x in range(w * ch):
-                a = cur[x - ch] if x >= ch else 0
-                b = prev[x]
-                c = prev[x - ch] if x >= ch else 0
-                if ft == 3:
-                    pr = (a + b) >> 1
-                else:
-                    pp = a + b - c
-                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
-                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[x] = (line[x] + pr) & 255
-        out[y] = cur
-        prev = cur
-    img = out.astype(np.uint8).reshape(h, w, ch)
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8)
+    assert raw.size == h * (1 + w * ch), "PNG size mismatch"
+    out = np.zeros(h * w * ch, np.uint8)
+    rc = lib().orc_png_unfilter(_fp(np.ascontiguousarray(raw)), _fp(out), w * ch, h, ch)
+    assert rc == 0, "bad PNG filter type"
+    img = out.reshape(h, w, ch)
     if ctype == 3:
         img = plte[img[:, :, 0]]
     return img
