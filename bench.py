@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X path-tracing back end.
+
+Metric (BASELINE.json): Mrays/s (primary + secondary) and ms/frame, 1280x720, 64 spp path trace, bunny.obj BVH-SAH
+(`configs[1]`).  A *step* = one pass of the hot path over one batch of synthetic input = clear the accumulator and
+render 64 frames (spp 1..64, passes = 1, depthLimit 5) of the bunny scene at 1280x720, inputs (BVH, triangles,
+textures) already resident in HBM.  Rays = FindNearest calls (primary + secondary), counted on the device.
+
+    python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Multi-GPU (weak scaling): every rank renders the full image for its OWN window of 64 frames
+(rank r: spp 1+64r .. 64+64r — (tile, frame) streams are independent, renderer.cpp:120), then the float4
+accumulators are summed with one RCCL all-reduce over xGMI; the job's image has 64*N spp.  `value` = rays of all
+ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the contract fields + "roofline" (dominant kernel = render_tiles_kernel, HIP events
+on the launch stream) + "cpu_baseline" (the CPU oracle on this box's host cores, bounded sample, rank 0, N = 1 only).
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+ASSETS = os.path.join(REPO, "assets")
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def load_crt():
+    spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["cpu_ray_tracer_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def algorithmic_bytes(c):
+    """64 B per interior iteration (both children), 40 B per triangle test, 64 B per BLAS visit,
+    76 B per mesh hit, 32 B per primary sample (float4 accumulate read + write)."""
+    return 64 * c["interior_iters"] + 40 * c["tri_tests"] + 64 * c["blas_visits"] + 76 * c["mesh_hits"] + 32 * c["primary"]
+
+
+def cpu_baseline(scene_xml, kind, W, H, budget_s=12.0):
+    """Times the CPU oracle (kind "port": the repo's restatement of the reference algorithm) on this box's cores."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import orc
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    o, _ = orc.load_scene(scene_xml, kind, ASSETS)
+    o.renderer_init(W, H)
+    o.render(1, threads)                       # warm-up frame (spp 1), also sizes the sample
+    o.reset_counters()
+    t0 = time.perf_counter()
+    o.render(1, threads)
+    one = time.perf_counter() - t0
+    frames = int(max(1, min(63, budget_s / max(one, 1e-3) - 1)))
+    t1 = time.perf_counter()
+    o.render(frames, threads)
+    dt = (time.perf_counter() - t1) + one
+    c = o.counters()
+    return {"value": round(c["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%d frames (spp 2..%d) of the same %dx%d bunny scene, %d threads, %.1f s" % (frames + 1, frames + 2, W, H, threads, dt),
+            "ms_per_frame": round(dt / (frames + 1) * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--scene", default="bunny_scene.xml")
+    ap.add_argument("--kind", type=int, default=0, help="0 = FileScene (single BVH), 1 = TLASFileScene")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: there is no CPU path for the product")
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    crt = load_crt()
+    W, H, SPP = args.width, args.height, args.spp
+    xml = os.path.join(ASSETS, "scenes", args.scene)
+    scene = crt.HostScene(xml, args.kind, ASSETS)                  # XML + OBJ + textures + SAH-BVH build on the CPU
+    ctx = crt.Context(W, H, device=device)
+    scene.upload(ctx)                                             # one-time flatten + copy to HBM
+    acc = torch.zeros(H, W, 4, dtype=torch.float32, device="cuda:%d" % device)
+    ctx.bind_accumulator(acc.data_ptr())
+    spp_first = 1 + rank * SPP
+
+    def step():
+        ctx.clear()
+        ctx.render(spp_first, SPP, 1)
+        ctx.sync()
+        if dist is not None:
+            dist.all_reduce(acc)                                  # RCCL sum of the float4 accumulators over xGMI
+            torch.cuda.synchronize()
+
+    # one counted pass with a statistics context (untimed) -> per-launch algorithmic bytes
+    sctx = crt.Context(W, H, device=device, collect_stats=True)
+    scene.upload(sctx)
+    sctx.render(spp_first, SPP, 1)
+    sctx.sync()
+    counts = sctx.counters()
+    sctx.close()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.reset_counters()
+    kernel_ms, acc_ms, launches = 0.0, 0.0, 0
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = ctx.timing()
+        kernel_ms += tm["render_kernel_ms"]; acc_ms += tm["resolve_kernel_ms"]; launches += tm["render_launches"]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    rays = ctx.counters()["rays"]
+    if dist is not None:
+        t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device="cuda:%d" % device)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+        rays = int(t[1].item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_step = elapsed / args.steps * 1e3
+    avg_launch_ms = kernel_ms / max(launches, 1)
+    launches_per_step = launches / args.steps
+    alg_bytes_launch = algorithmic_bytes(counts) / max(launches_per_step, 1)
+    achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("render_tiles_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "Mrays/sec (primary+secondary), 1280x720 64spp path trace",
+        "value": round(rays / elapsed / 1e6, 2),
+        "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4),
+        "ms_per_frame": round(ms_step / SPP, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %s BVH-SAH path tracer, %dx%d, %d spp/step (passes=1, depthLimit=5), 1 step = clear + %d frames%s"
+                               % (args.scene, "TLASFileScene" if args.kind else "FileScene", W, H, SPP, SPP,
+                                  "" if world == 1 else "; rank r renders spp window [1+%d r, %d+%d r], RCCL all-reduce of the float4 accumulator" % (SPP, SPP, SPP)),
+                   "rays_per_step_rank0": counts["rays"], "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
+                   "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "kernel": "render_tiles_kernel", "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": launches_per_step,
+                     "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+                     "accumulate_kernel_ms_per_step": round(acc_ms / args.steps, 4),
+                     "counters_per_step": counts},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(xml, args.kind, W, H)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

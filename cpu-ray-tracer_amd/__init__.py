@@ -53,7 +53,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("objIdx", "<i4"
 # every symbol include/crt_abi.h and include/crt_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = ["crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
                "crt_render", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
-               "crt_reset_counters", "crt_get_timing", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
+               "crt_reset_counters", "crt_get_timing", "crt_get_tile_clocks", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
 HOST_SYMBOLS = ["crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
                 "crt_host_scene_triangle_count", "crt_host_scene_bvh_count", "crt_host_scene_bvh_info", "crt_host_scene_bvh_copy",
                 "crt_host_scene_blas_transform", "crt_host_scene_tlas_copy", "crt_host_camera_state", "crt_host_renderer_create",
@@ -203,6 +203,11 @@ class Context:
         t = TimingS()
         self._ck(self.L.crt_get_timing(self.h, C.byref(t)))
         return dict(render_kernel_ms=t.render_kernel_ms, resolve_kernel_ms=t.resolve_kernel_ms, render_launches=t.render_launches)
+
+    def tile_clocks(self, tile_count):
+        a = np.zeros((tile_count, 2), np.uint64)
+        self._ck(self.L.crt_get_tile_clocks(self.h, _p(a)))
+        return a
 
     def bind_accumulator(self, device_ptr):
         self._ck(self.L.crt_bind_accumulator(self.h, C.c_void_p(device_ptr)))

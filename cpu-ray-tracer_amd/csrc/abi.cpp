@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_resolve(const void*, uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float, hipStream_t);
@@ -39,9 +39,10 @@ struct crt_ctx {
     // device memory
     void* dAccOwned = nullptr; void* dAcc = nullptr;
     void* dSlab = nullptr; size_t slabBytes = 0;
-    crt::Scene hScene{}; crt::Scene* dScene = nullptr;
+    crt::Scene hScene{};
     crt::Counters* dCounters = nullptr;
     uint32_t* dPixels = nullptr; float* dTileSums = nullptr;
+    unsigned long long* dTileClocks = nullptr;
     std::vector<void*> sceneAllocs;
     bool haveScene = false;
     uint32_t ldsBytes = 0;
@@ -102,17 +103,18 @@ int bvh_height(crt_ctx* c, const crt_bvh& b, uint32_t* heightOut)
     return 0;
 }
 
-int node_ref(crt_ctx* c, const crt_bvh& b, uint32_t n, uint32_t* ref)
+// packed GLOBAL reference of node n of BVH b whose pairs / leaf slots start at pairBase / leafBase (layout.h)
+int node_ref(crt_ctx* c, const crt_bvh& b, uint32_t n, uint32_t pairBase, uint32_t leafBase, uint32_t* ref)
 {
     const crt_bvh_node& nd = b.nodes[n];
     if (nd.triCount > 0) {
         if (nd.triCount > crt::kMaxLeafTris)
             return c->fail(CRT_ERR_UNSUPPORTED, "leaf with %u triangles: this build packs at most %u per leaf", nd.triCount, crt::kMaxLeafTris);
         if ((uint64_t)nd.leftFirst + nd.triCount > b.triCount) return c->fail(CRT_ERR_INVALID, "leaf range out of bounds (node %u)", n);
-        *ref = (nd.triCount << 24) | nd.leftFirst;
+        *ref = (nd.triCount << 24) | (leafBase + nd.leftFirst);
     } else {
         if ((nd.leftFirst & 1u) == 0) return c->fail(CRT_ERR_INVALID, "interior node %u: children must be allocated pairwise starting at an odd index", n);
-        *ref = crt::kInteriorFlag | ((nd.leftFirst - 1u) >> 1);
+        *ref = crt::kRefInterior | (pairBase + ((nd.leftFirst - 1u) >> 1));
     }
     return 0;
 }
@@ -174,7 +176,10 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     if ((e = hipMemsetAsync(c->dTileSums, 0, (size_t)tiles * 4, c->stream)) != hipSuccess) return bail(e, "hipMemset(tileSums)");
     if ((e = hipMalloc((void**)&c->dCounters, sizeof(crt::Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemsetAsync(c->dCounters, 0, sizeof(crt::Counters), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
-    if ((e = hipMalloc((void**)&c->dScene, sizeof(crt::Scene))) != hipSuccess) return bail(e, "hipMalloc(scene)");
+    if (c->cfg.collectStats && count > 0) {
+        if ((e = hipMalloc((void**)&c->dTileClocks, (size_t)count * 16)) != hipSuccess) return bail(e, "hipMalloc(tileClocks)");
+        if ((e = hipMemsetAsync(c->dTileClocks, 0, (size_t)count * 16, c->stream)) != hipSuccess) return bail(e, "hipMemset(tileClocks)");
+    }
     // Camera() defaults, template/camera.h:14-22
     memset(&c->hScene, 0, sizeof(c->hScene));
     const float aspect = (float)cfg->width / (float)cfg->height;
@@ -202,7 +207,7 @@ void crt_destroy(crt_ctx* c)
     if (c->dPixels) (void)hipFree(c->dPixels);
     if (c->dTileSums) (void)hipFree(c->dTileSums);
     if (c->dCounters) (void)hipFree(c->dCounters);
-    if (c->dScene) (void)hipFree(c->dScene);
+    if (c->dTileClocks) (void)hipFree(c->dTileClocks);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -235,19 +240,19 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         uint32_t h = 0; int r = bvh_height(c, b, &h); if (r) return r;
         if (h > maxHeight) maxHeight = h;
         const uint32_t pairBase = (uint32_t)pairs.size(), leafBase = (uint32_t)leaf.size(), shadeBase = (uint32_t)shade.size();
-        if ((uint64_t)leafBase + b.triCount > crt::kMaxLeafSlots && sd->kind == CRT_SCENE_FILE) return c->fail(CRT_ERR_UNSUPPORTED, "more than 2^24 triangles in one BVH");
-        if (b.triCount > crt::kMaxLeafSlots) return c->fail(CRT_ERR_UNSUPPORTED, "more than 2^24 triangles in one BVH");
+        if ((uint64_t)leafBase + b.triCount > crt::kMaxLeafSlots) return c->fail(CRT_ERR_UNSUPPORTED, "more than 2^24 triangles in the scene");
+        if ((uint64_t)pairBase + b.nodesUsed / 2 > crt::kMaxPairs) return c->fail(CRT_ERR_UNSUPPORTED, "more than 2^30 node pairs in the scene");
         // node pairs
         for (uint32_t n = 1; n + 1 < b.nodesUsed; n += 2) {
             crt::NodePair p; memset(&p, 0, sizeof(p));
             for (int k = 0; k < 2; k++) {
                 const crt_bvh_node& nd = b.nodes[n + k];
                 memcpy(p.c[k].lo, nd.aabbMin, 12); memcpy(p.c[k].hi, nd.aabbMax, 12);
-                r = node_ref(c, b, n + k, &p.c[k].ref); if (r) return r;
+                r = node_ref(c, b, n + k, pairBase, leafBase, &p.c[k].ref); if (r) return r;
             }
             pairs.push_back(p);
         }
-        uint32_t rootRef = 0; r = node_ref(c, b, 0, &rootRef); if (r) return r;
+        uint32_t rootRef = 0; r = node_ref(c, b, 0, pairBase, leafBase, &rootRef); if (r) return r;
         // triangles in leaf order + shading records in triIdx order
         for (uint32_t j = 0; j < b.triCount; j++) {
             const uint32_t ti = b.triangleIndices[j];
@@ -273,17 +278,22 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
             if (b.objIdx != (int)bi + 2) return c->fail(CRT_ERR_INVALID, "BLAS %u: objIdx must be %u (TLASFileScene numbers objects from 2, tlas_file_scene.cpp:13,51-53)", bi, bi + 2);
             crt::Instance in; memset(&in, 0, sizeof(in));
             memcpy(in.invT, b.invT, 48); memcpy(in.T, b.T, 48);
-            in.pairBase = pairBase; in.leafBase = leafBase; in.shadeBase = shadeBase; in.matIdx = b.matIdx; in.rootRef = rootRef; in.objIdx = b.objIdx;
+            in.shadeBase = shadeBase; in.matIdx = b.matIdx; in.rootRef = rootRef; in.objIdx = b.objIdx;
             inst.push_back(in);
         } else {
             rootRef0 = rootRef;
         }
     }
-    // LeafTri refs inside a BLAS are local to its leafBase (the kernel offsets the pointer); for the single BVH leafBase is 0.
     std::vector<crt::TlasNode> tlas; uint32_t tlasHeight = 0, tlasRoot = 0;
     if (sd->kind == CRT_SCENE_TLAS) {
+        if (sd->tlasNodeCount > 0x7fffu) return c->fail(CRT_ERR_UNSUPPORTED, "TLAS node index exceeds 15 bits");
         tlas.resize(sd->tlasNodeCount);
-        memcpy(tlas.data(), sd->tlasNodes, sizeof(crt::TlasNode) * sd->tlasNodeCount);
+        for (uint32_t i = 0; i < sd->tlasNodeCount; i++) {      // device copy carries each node's packed reference instead of leftRight / BLAS
+            const crt_tlas_node& nd = sd->tlasNodes[i];
+            memcpy(tlas[i].lo, nd.aabbMin, 12); memcpy(tlas[i].hi, nd.aabbMax, 12); tlas[i].pad = 0;
+            tlas[i].ref = nd.leftRight ? (crt::kRefTlasInterior | (nd.leftRight & 0x7fffu) | (((nd.leftRight >> 16) & 0x7fffu) << 15))
+                                       : (crt::kRefTlasLeaf | (nd.BLAS & 0xffffu));
+        }
         // validate + height
         std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 0u}); size_t visited = 0;
         while (!st.empty()) {
@@ -292,11 +302,10 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
             const crt_tlas_node& nd = sd->tlasNodes[n];
             if (nd.leftRight == 0) { if (nd.BLAS >= sd->bvhCount) return c->fail(CRT_ERR_INVALID, "TLAS leaf references BLAS %u", nd.BLAS); if (d > tlasHeight) tlasHeight = d; continue; }
             const uint32_t l = nd.leftRight & 0xffffu, r = nd.leftRight >> 16;
-            if (l >= sd->tlasNodeCount || r >= sd->tlasNodeCount || (nd.leftRight & crt::kInteriorFlag)) return c->fail(CRT_ERR_INVALID, "TLAS child index out of range");
+            if (l >= sd->tlasNodeCount || r >= sd->tlasNodeCount) return c->fail(CRT_ERR_INVALID, "TLAS child index out of range");
             st.push_back({l, d + 1}); st.push_back({r, d + 1});
         }
-        const crt_tlas_node& root = sd->tlasNodes[0];
-        tlasRoot = root.leftRight ? root.leftRight : (crt::kInteriorFlag | root.BLAS);
+        tlasRoot = tlas[0].ref;
     }
     // materials: [0] light, [1] floor, then the scene's (file_scene.cpp:10-12, 30-38)
     std::vector<crt::Material> mats(2 + sd->materialCount);
@@ -345,11 +354,10 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     if ((r = upload(c, tlas, &s.tlas))) return r;
     if ((r = upload(c, inst, &s.inst))) return r;
     s.rootRef = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot : rootRef0;
-    s.bvhStack = maxHeight + 2; s.tlasStack = (sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 2 : 0;
-    c->ldsBytes = (s.bvhStack + s.tlasStack) * 64u * 4u;
+    s.bvhStack = maxHeight + 2;
+    s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 3 : 0);   // + TLAS pushes + the return marker + slack
+    c->ldsBytes = s.stackDepth * 64u * 4u;
     if (c->ldsBytes > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "tree height %u (+TLAS %u) needs %u bytes of LDS traversal stack per wave (> 64 KiB)", maxHeight, tlasHeight, c->ldsBytes);
-    HIPCK(c, hipMemcpyAsync(c->dScene, &c->hScene, sizeof(crt::Scene), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
     c->haveScene = true;
     return CRT_OK;
 }
@@ -359,10 +367,7 @@ int crt_set_camera(crt_ctx* c, const float camPos[3], const float tl[3], const f
     if (!c || !camPos || !tl || !tr || !bl) return CRT_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->cfg.device));
     memcpy(c->hScene.camPos, camPos, 12); memcpy(c->hScene.topLeft, tl, 12); memcpy(c->hScene.topRight, tr, 12); memcpy(c->hScene.bottomLeft, bl, 12);
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    HIPCK(c, hipMemcpyAsync(c->dScene, &c->hScene, sizeof(crt::Scene), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    return CRT_OK;
+    return CRT_OK;      // the Scene block travels by value in every launch's kernel arguments
 }
 
 static int take_event(crt_ctx* c, std::vector<EventPair>& list, EventPair* out)
@@ -399,7 +404,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         EventPair ev; int r;
         if ((r = take_event(c, c->evRender, &ev))) return r;
         HIPCK(c, hipEventRecord(ev.a, c->stream));
-        HIPCK(c, crt_launch_render(c->dScene, c->dSlab, c->dCounters, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+        HIPCK(c, crt_launch_render(&c->hScene, c->dSlab, c->dCounters, c->dTileClocks, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
                                    spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, c->stream));
         HIPCK(c, hipEventRecord(ev.b, c->stream));
         if ((r = take_event(c, c->evAcc, &ev))) return r;
@@ -463,7 +468,7 @@ int crt_find_nearest(crt_ctx* c, const crt_ray* rays, crt_hit* hits, size_t n)
     int rc = CRT_OK;
     do {
         if ((e = hipMemcpyAsync(dR, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, c->stream)) != hipSuccess) { rc = c->hip(e, "copy rays"); break; }
-        if ((e = crt_launch_find_nearest(c->dScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->stream)) != hipSuccess) { rc = c->hip(e, "launch find_nearest"); break; }
+        if ((e = crt_launch_find_nearest(&c->hScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->stream)) != hipSuccess) { rc = c->hip(e, "launch find_nearest"); break; }
         if ((e = hipMemcpyAsync(hits, dH, n * sizeof(crt_hit), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) { rc = c->hip(e, "copy hits"); break; }
         if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { rc = c->hip(e, "sync"); break; }
     } while (0);
@@ -497,6 +502,16 @@ int crt_get_timing(crt_ctx* c, crt_timing* out)
     for (auto& ev : c->evRender) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->render_kernel_ms += ms; }
     for (auto& ev : c->evAcc) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->resolve_kernel_ms += ms; }
     out->render_launches = (uint32_t)c->evRender.size();
+    return CRT_OK;
+}
+
+int crt_get_tile_clocks(crt_ctx* c, uint64_t* out)
+{
+    if (!c || !out) return CRT_ERR_INVALID;
+    if (!c->dTileClocks) return c->fail(CRT_ERR_STATE, "tile clocks are recorded only by a collectStats context");
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMemcpyAsync(out, c->dTileClocks, (size_t)c->tileCount * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
 }
 

@@ -2,10 +2,14 @@
 //
 //   render_tiles_kernel   one 64-lane wavefront per 16x16 image tile; lane f owns the RNG stream of frame f of that
 //                         tile (the reference seeds one xorshift32 stream per (tile, frame) and consumes it serially
-//                         over the tile's 256 pixels — "3. PathTracer/renderer.cpp":117-131).  Every loop iteration
-//                         of a lane traces exactly one ray (ray-gen / traverse / shade phases, path regeneration when a
-//                         path ends), so the wave never idles on short paths.  Traversal stacks are per-lane columns
-//                         in LDS.  Each finished path writes its radiance sample to the sample slab in HBM.
+//                         over the tile's 256 pixels — "3. PathTracer/renderer.cpp":117-131).  The wave is a small
+//                         wavefront pipeline of its own: every lane is a state machine {needs shading / ray-gen,
+//                         at a TLAS node, at a BVH interior node, at a leaf triangle}, and each trip of the wave's
+//                         loop executes ONE phase, chosen from __ballot population counts, for the lanes that are in
+//                         it.  Lanes never wait for the longest ray of the wave: a lane whose path ends regenerates
+//                         its next pixel's primary ray and re-enters traversal while its neighbours keep walking.
+//                         Traversal stacks are per-lane columns in LDS.  Finished paths write their radiance sample
+//                         to the sample slab in HBM.
 //   accumulate_kernel     adds the slab's samples to the float4 accumulator in frame order (bit-exact with the
 //                         reference's `accumulator[..] +=` order, renderer.cpp:124) — no float atomics anywhere.
 //   find_nearest_kernel   scene.FindNearest for a ray buffer (parity / query entry).
@@ -130,13 +134,19 @@ __device__ __forceinline__ float rnd(uint32_t& s)
     return (float)s * 2.3283064365387e-10f;
 }
 
+
 struct Hit { float t, u, v; int objIdx, triIdx; };
 struct Cnt { uint32_t rays, primary, interior, leaf, tri, tlas, visits, meshhits; };
 
 __device__ __forceinline__ float4 ld4(const void* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ bool finite3(f3 v)
+{
+    const uint32_t m = 0x7f800000u;
+    return ((asu(v.x) & m) != m) && ((asu(v.y) & m) != m) && ((asu(v.z) & m) != m);
+}
 
-// slab test, infra/bvh.cpp:181-190
-__device__ __forceinline__ float slab(float4 lo, float4 hi, f3 O, f3 rD, float tray)
+// slab test, infra/bvh.cpp:181-190, with the reference's std::min / std::max operand order (NaN-exact)
+__device__ __forceinline__ float box_exact(float4 lo, float4 hi, f3 O, f3 rD, float tray)
 {
     float tx1 = (lo.x - O.x) * rD.x, tx2 = (hi.x - O.x) * rD.x;
     float tmin = min_std(tx1, tx2), tmax = max_std(tx1, tx2);
@@ -146,66 +156,42 @@ __device__ __forceinline__ float slab(float4 lo, float4 hi, f3 O, f3 rD, float t
     tmin = max_std(tmin, min_std(tz1, tz2)); tmax = min_std(tmax, max_std(tz1, tz2));
     return (tmax >= tmin && tmin < tray && tmax > 0) ? tmin : 1e30f;
 }
-
-// ordered stack traversal of one BVH (infra/bvh.cpp:224-258); stack = this lane's LDS column (stride 64 dwords)
-template <bool COUNT>
-__device__ __forceinline__ void traverse_bvh(const NodePair* __restrict__ pairs, const LeafTri* __restrict__ leaf, uint32_t rootRef,
-                                             f3 O, f3 D, f3 rD, Hit& h, uint32_t* stk, Cnt& cn, int& traversed, int& tested)
+// same test with v_min/v_max(3): identical decisions whenever no product is NaN, i.e. whenever all three rD are
+// finite (0 * inf is the only NaN source); the sign of a zero result never reaches a comparison that can tell.
+__device__ __forceinline__ float box_fast(float4 lo, float4 hi, f3 O, f3 rD, float tray)
 {
-    uint32_t cur = rootRef, sp = 0;
-    for (;;) {
-        traversed++;
-        if (cur & kInteriorFlag) {
-            if (COUNT) cn.interior++;
-            const char* p = reinterpret_cast<const char*>(pairs + (cur & 0x7fffffffu));
-            float4 alo = ld4(p), ahi = ld4(p + 16), blo = ld4(p + 32), bhi = ld4(p + 48);
-            float d1 = slab(alo, ahi, O, rD, h.t), d2 = slab(blo, bhi, O, rD, h.t);
-            uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
-            if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
-            if (d1 == 1e30f) {
-                if (sp == 0) break;
-                cur = stk[(--sp) * 64];
-            } else {
-                cur = r1;
-                if (d2 != 1e30f) { stk[sp * 64] = r2; sp++; }
-            }
-        } else {
-            if (COUNT) cn.leaf++;
-            uint32_t first = cur & 0xffffffu, cnt = cur >> 24;
-            for (uint32_t i = 0; i < cnt; i++) {
-                const char* p = reinterpret_cast<const char*>(leaf + first + i);
-                float4 a = ld4(p), b = ld4(p + 16), c = ld4(p + 32);
-                tested++;
-                if (COUNT) cn.tri++;
-                // Möller–Trumbore, infra/bvh.cpp:203-222
-                f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
-                f3 hh = cross3(D, e2);
-                float det = dot3(e1, hh);
-                if (det > -0.0001f && det < 0.0001f) continue;
-                float f = 1 / det;
-                f3 s = O - v0;
-                float u = f * dot3(s, hh);
-                if (u < 0 || u > 1) continue;
-                f3 q = cross3(s, e1);
-                float v = f * dot3(D, q);
-                if (v < 0 || u + v > 1) continue;
-                float t = f * dot3(e2, q);
-                if (t > 0.0001f && t < h.t) { h.t = t; h.u = u; h.v = v; h.triIdx = (int)asu(a.w); h.objIdx = (int)asu(b.w); }
-            }
-            if (sp == 0) break;
-            cur = stk[(--sp) * 64];
-        }
-    }
+    float tx1 = (lo.x - O.x) * rD.x, tx2 = (hi.x - O.x) * rD.x;
+    float ty1 = (lo.y - O.y) * rD.y, ty2 = (hi.y - O.y) * rD.y;
+    float tz1 = (lo.z - O.z) * rD.z, tz2 = (hi.z - O.z) * rD.z;
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
+    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
+    return (tmax >= tmin && tmin < tray && tmax > 0) ? tmin : 1e30f;
 }
 
-// scene.FindNearest: light quad, floor plane, then BVH or TLAS (file_scene.cpp:170-175, tlas_file_scene.cpp:201-206)
-template <bool COUNT>
-__device__ __forceinline__ void find_nearest(const Scene* __restrict__ sc, f3 O, f3 D, f3 rD, Hit& h, uint32_t* stk, Cnt& cn,
-                                             int& traversed, int& tested)
+// Möller–Trumbore against one LeafTri, infra/bvh.cpp:203-222 (strict '<' keeps the first of equal hits)
+__device__ __forceinline__ void hit_tri(const LeafTri* __restrict__ leaf, uint32_t slot, f3 O, f3 D, Hit& h)
 {
-    cn.rays++;
-    {   // Quad::Intersect, template/primitives.h:331-346
-        const float* c = sc->lightInvT;
+    const char* p = reinterpret_cast<const char*>(leaf + slot);
+    const float4 a = ld4(p), b = ld4(p + 16), c = ld4(p + 32);
+    const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+    const f3 hh = cross3(D, e2);
+    const float det = dot3(e1, hh);
+    const float f = 1 / det;
+    const f3 s = O - v0;
+    const float u = f * dot3(s, hh);
+    const f3 q = cross3(s, e1);
+    const float v = f * dot3(D, q);
+    const float t = f * dot3(e2, q);
+    const bool ok = !(det > -0.0001f && det < 0.0001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1) && (t > 0.0001f) && (t < h.t);
+    if (ok) { h.t = t; h.u = u; h.v = v; h.triIdx = (int)asu(a.w); h.objIdx = (int)asu(b.w); }
+}
+
+// Quad::Intersect + Plane::Intersect (template/primitives.h:331-346, 107-111): the two analytic primitives FindNearest
+// tests before the acceleration structure (file_scene.cpp:170-175)
+__device__ __forceinline__ void hit_light_floor(const Scene& sc, f3 O, f3 D, Hit& h)
+{
+    {
+        const float* c = sc.lightInvT;
         const float Oy = c[4] * O.x + c[5] * O.y + c[6] * O.z + c[7];
         const float Dy = c[4] * D.x + c[5] * D.y + c[6] * D.z;
         const float t = Oy / -Dy;
@@ -215,56 +201,86 @@ __device__ __forceinline__ void find_nearest(const Scene* __restrict__ sc, f3 O,
             const float Dx = c[0] * D.x + c[1] * D.y + c[2] * D.z;
             const float Dz = c[8] * D.x + c[9] * D.y + c[10] * D.z;
             const float Ix = Ox + t * Dx, Iz = Oz + t * Dz;
-            const float size = sc->lightSize;
+            const float size = sc.lightSize;
             if (Ix > -size && Ix < size && Iz > -size && Iz < size) { h.t = t; h.objIdx = 0; }
         }
     }
-    {   // Plane::Intersect, template/primitives.h:107-111
-        f3 N = mk3(sc->floorN[0], sc->floorN[1], sc->floorN[2]);
-        float t = -(dot3(O, N) + sc->floorD) / (dot3(D, N));
+    {
+        const f3 N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
+        const float t = -(dot3(O, N) + sc.floorD) / (dot3(D, N));
         if (t < h.t && t > 0) { h.t = t; h.objIdx = 1; }
     }
-    if (sc->kind == 0) {
-        traverse_bvh<COUNT>(sc->pairs, sc->leaf, sc->rootRef, O, D, rD, h, stk, cn, traversed, tested);
+}
+
+// BLASBVH::Intersect's ray transform (infra/blas_bvh.cpp:376-381): invT rows, SSE summation order (x+y)+(z+w) / (x+y)+z
+__device__ __forceinline__ void to_object_space(const Instance* __restrict__ in, f3 O, f3 D, f3& Oo, f3& Do, f3& rDo)
+{
+    const float4 r0 = ld4(in->invT), r1 = ld4(in->invT + 4), r2 = ld4(in->invT + 8);
+    Oo = mk3((O.x * r0.x + O.y * r0.y) + (O.z * r0.z + 1.0f * r0.w),
+             (O.x * r1.x + O.y * r1.y) + (O.z * r1.z + 1.0f * r1.w),
+             (O.x * r2.x + O.y * r2.y) + (O.z * r2.z + 1.0f * r2.w));
+    Do = mk3((D.x * r0.x + D.y * r0.y) + D.z * r0.z,
+             (D.x * r1.x + D.y * r1.y) + D.z * r1.z,
+             (D.x * r2.x + D.y * r2.y) + D.z * r2.z);
+    rDo = mk3(1 / Do.x, 1 / Do.y, 1 / Do.z);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// sequential reference-order traversal (used by find_nearest_kernel: it reports Ray::traversed / tested, which
+// count loop trips in the reference's order — infra/bvh.cpp:224-258, infra/tlas_bvh.cpp:83-111)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void traverse_bvh_seq(const Scene& sc, uint32_t rootRef, f3 O, f3 D, f3 rD, Hit& h, uint32_t* stk, Cnt& cn,
+                                                 int& traversed, int& tested)
+{
+    uint32_t cur = rootRef, sp = 0;
+    for (;;) {
+        traversed++;
+        if (cur & kRefInterior) {
+            cn.interior++;
+            const char* p = reinterpret_cast<const char*>(sc.pairs + (cur & 0x3fffffffu));
+            const float4 alo = ld4(p), ahi = ld4(p + 16), blo = ld4(p + 32), bhi = ld4(p + 48);
+            float d1 = box_exact(alo, ahi, O, rD, h.t), d2 = box_exact(blo, bhi, O, rD, h.t);
+            uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
+            if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+            if (d1 == 1e30f) { if (sp == 0) break; cur = stk[(--sp) * 64]; }
+            else { cur = r1; if (d2 != 1e30f) { stk[sp * 64] = r2; sp++; } }
+        } else {
+            cn.leaf++;
+            const uint32_t first = cur & 0xffffffu, cnt = cur >> 24;
+            for (uint32_t i = 0; i < cnt; i++) { tested++; cn.tri++; hit_tri(sc.leaf, first + i, O, D, h); }
+            if (sp == 0) break;
+            cur = stk[(--sp) * 64];
+        }
+    }
+}
+
+__device__ __forceinline__ void find_nearest_seq(const Scene& sc, f3 O, f3 D, f3 rD, Hit& h, uint32_t* stk, Cnt& cn, int& traversed, int& tested)
+{
+    cn.rays++;
+    hit_light_floor(sc, O, D, h);
+    if (sc.kind == 0) {
+        traverse_bvh_seq(sc, sc.rootRef, O, D, rD, h, stk, cn, traversed, tested);
     } else {
-        // TLASBVH::Intersect, infra/tlas_bvh.cpp:83-111.  packed ref: leaf = flag | BLAS, interior = leftRight
-        uint32_t* tstk = stk + sc->bvhStack * 64;
-        const TlasNode* __restrict__ tl = sc->tlas;
-        uint32_t cur = sc->rootRef, sp = 0;
+        uint32_t* tstk = stk + sc.bvhStack * 64;     // TLAS entries live above the BVH part of this lane's column
+        uint32_t cur = sc.rootRef, sp = 0;
         for (;;) {
-            traversed++;
-            if (COUNT) cn.tlas++;
-            if (cur & kInteriorFlag) {
-                // BLASBVH::Intersect, infra/blas_bvh.cpp:376-389: ray to object space through invT, SSE summation order
-                if (COUNT) cn.visits++;
-                const Instance* in = sc->inst + (cur & 0xffffu);
-                float4 r0 = ld4(in->invT), r1 = ld4(in->invT + 4), r2 = ld4(in->invT + 8);
-                f3 Oo = mk3((O.x * r0.x + O.y * r0.y) + (O.z * r0.z + 1.0f * r0.w),
-                            (O.x * r1.x + O.y * r1.y) + (O.z * r1.z + 1.0f * r1.w),
-                            (O.x * r2.x + O.y * r2.y) + (O.z * r2.z + 1.0f * r2.w));
-                f3 Do = mk3((D.x * r0.x + D.y * r0.y) + D.z * r0.z,
-                            (D.x * r1.x + D.y * r1.y) + D.z * r1.z,
-                            (D.x * r2.x + D.y * r2.y) + D.z * r2.z);
-                f3 rDo = mk3(1 / Do.x, 1 / Do.y, 1 / Do.z);
-                traverse_bvh<COUNT>(sc->pairs + in->pairBase, sc->leaf + in->leafBase, in->rootRef, Oo, Do, rDo, h, stk, cn, traversed, tested);
+            traversed++; cn.tlas++;
+            if ((cur & kRefTlasLeaf) == kRefTlasLeaf) {
+                cn.visits++;
+                const Instance* in = sc.inst + (cur & 0xffffu);
+                f3 Oo, Do, rDo; to_object_space(in, O, D, Oo, Do, rDo);
+                traverse_bvh_seq(sc, in->rootRef, Oo, Do, rDo, h, stk, cn, traversed, tested);
                 if (sp == 0) break;
                 cur = tstk[(--sp) * 64];
             } else {
-                const char* p1 = reinterpret_cast<const char*>(tl + (cur & 0xffffu));
-                const char* p2 = reinterpret_cast<const char*>(tl + (cur >> 16));
-                float4 alo = ld4(p1), ahi = ld4(p1 + 16), blo = ld4(p2), bhi = ld4(p2 + 16);
-                float d1 = slab(alo, ahi, O, rD, h.t), d2 = slab(blo, bhi, O, rD, h.t);
-                uint32_t lr1 = asu(alo.w), lr2 = asu(blo.w);
-                uint32_t r1 = lr1 ? lr1 : (kInteriorFlag | asu(ahi.w));
-                uint32_t r2 = lr2 ? lr2 : (kInteriorFlag | asu(bhi.w));
+                const char* p1 = reinterpret_cast<const char*>(sc.tlas + (cur & 0x7fffu));
+                const char* p2 = reinterpret_cast<const char*>(sc.tlas + ((cur >> 15) & 0x7fffu));
+                const float4 alo = ld4(p1), ahi = ld4(p1 + 16), blo = ld4(p2), bhi = ld4(p2 + 16);
+                float d1 = box_exact(alo, ahi, O, rD, h.t), d2 = box_exact(blo, bhi, O, rD, h.t);
+                uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
                 if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
-                if (d1 == 1e30f) {
-                    if (sp == 0) break;
-                    cur = tstk[(--sp) * 64];
-                } else {
-                    cur = r1;
-                    if (d2 != 1e30f) { tstk[sp * 64] = r2; sp++; }
-                }
+                if (d1 == 1e30f) { if (sp == 0) break; cur = tstk[(--sp) * 64]; }
+                else { cur = r1; if (d2 != 1e30f) { tstk[sp * 64] = r2; sp++; } }
             }
         }
     }
@@ -272,58 +288,58 @@ __device__ __forceinline__ void find_nearest(const Scene* __restrict__ sc, f3 O,
 }
 
 // Texture::Sample, template/texture.h:61-96
-__device__ __forceinline__ f3 tex_sample(const Scene* __restrict__ sc, int id, float u, float v)
+__device__ __forceinline__ f3 tex_sample(const Scene& sc, int id, float u, float v)
 {
-    const TexDesc td = sc->tex[id];
+    const TexDesc td = sc.tex[id];
     u = clamp_tm(u, 0.0f, 1.0f);
     v = 1 - clamp_tm(v, 0.0f, 1.0f);
     int x = (int)(u * td.w), y = (int)(v * td.h);
     x = clampi(x, 0, td.w - 1); y = clampi(y, 0, td.h - 1);
-    uint32_t p = sc->texels[(size_t)td.offset + (size_t)x + (size_t)y * (size_t)td.w];
+    uint32_t p = sc.texels[(size_t)td.offset + (size_t)x + (size_t)y * (size_t)td.w];
     const float s = 1 / 255.0f;
     return mk3(((p >> 16) & 0xFF) * s, ((p >> 8) & 0xFF) * s, (p & 0xFF) * s);
 }
 
 // GetSkyColor, infra/scene/file_scene.cpp:142-154
-__device__ __forceinline__ f3 sky_color(const Scene* __restrict__ sc, f3 D)
+__device__ __forceinline__ f3 sky_color(const Scene& sc, f3 D)
 {
     float phi = crt_atan2f(-D.z, D.x) + CRT_PI;
     float theta = crt_acosf(-D.y);
-    return tex_sample(sc, sc->skyTex, phi * CRT_INV2PI, theta * CRT_INVPI);
+    return tex_sample(sc, sc.skyTex, phi * CRT_INV2PI, theta * CRT_INVPI);
 }
 
 // One bounce of Renderer::Sample ("3. PathTracer/renderer.cpp":50-100) after FindNearest.
 // Returns true when the path ends (L = terminal radiance); otherwise writes the throughput factor of this
 // depth and the continuation ray.
-__device__ __forceinline__ bool shade(const Scene* __restrict__ sc, const Hit& h, f3& O, f3& D, f3& rD, bool& inside,
+__device__ __forceinline__ bool shade(const Scene& sc, const Hit& h, f3& O, f3& D, f3& rD, bool& inside,
                                       int depth, uint32_t& seed, f3& factor, f3& L)
 {
     if (h.objIdx == -1) { L = sky_color(sc, D); return true; }
-    if (depth >= sc->depthLimit) { L = mk3(0, 0, 0); return true; }
+    if (depth >= sc.depthLimit) { L = mk3(0, 0, 0); return true; }
     if (h.objIdx == 0) { L = mk3(24, 24, 22); return true; }        // light: GetLightColor (file_scene.cpp:164-167)
     f3 I = O + h.t * D;
     f3 N; float tu = 0, tv = 0; int mat;
     if (h.objIdx == 1) {                                              // floor: Plane::GetNormal / GetUV (primitives.h:112-133)
-        N = mk3(sc->floorN[0], sc->floorN[1], sc->floorN[2]);
+        N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
         if (N.y == 1) {
             float u = I.x, v = I.z;
-            u *= sc->floorInvto; v *= sc->floorInvto;
+            u *= sc.floorInvto; v *= sc.floorInvto;
             tu = u - __builtin_floorf(u); tv = v - __builtin_floorf(v);
         }
         mat = 1;
     } else {                                                          // mesh: GetNormal / GetUV (bvh.cpp:290-305, blas_bvh.cpp:391-406)
         uint32_t base = 0; const Instance* in = nullptr;
-        if (sc->kind != 0) { in = sc->inst + (h.objIdx - 2); base = in->shadeBase; }
-        const char* p = reinterpret_cast<const char*>(sc->shade + base + (uint32_t)h.triIdx);
+        if (sc.kind != 0) { in = sc.inst + (h.objIdx - 2); base = in->shadeBase; }
+        const char* p = reinterpret_cast<const char*>(sc.shade + base + (uint32_t)h.triIdx);
         float4 a = ld4(p), b = ld4(p + 16), c = ld4(p + 32), d = ld4(p + 48);
         f3 n0 = mk3(a.x, a.y, a.z), n1 = mk3(a.w, b.x, b.y), n2 = mk3(b.z, b.w, c.x);
         float w = 1 - h.u - h.v;
         f3 Nn = w * n0 + h.u * n1 + h.v * n2;
         tu = w * c.y + h.u * c.w + h.v * d.y;
         tv = w * c.z + h.u * d.x + h.v * d.z;
-        if (sc->kind == 0) {
+        if (sc.kind == 0) {
             N = normalize3(Nn);
-            mat = sc->objMat[(int)asu(d.w) - 2] + 2;
+            mat = sc.objMat[(int)asu(d.w) - 2] + 2;
         } else {
             float4 r0 = ld4(in->T), r1 = ld4(in->T + 4), r2 = ld4(in->T + 8);
             f3 Nt = mk3(r0.x * Nn.x + r0.y * Nn.y + r0.z * Nn.z + r0.w * 0.0f,
@@ -334,7 +350,7 @@ __device__ __forceinline__ bool shade(const Scene* __restrict__ sc, const Hit& h
         }
     }
     if (dot3(N, D) > 0) N = -N;
-    const Material m = sc->mats[mat];
+    const Material m = sc.mats[mat];
     f3 albedo = (m.tex >= 0) ? tex_sample(sc, m.tex, tu, tv) : mk3(1.0f, 1.0f, 1.0f);
     f3 medium = mk3(1, 1, 1);
     if (inside) {
@@ -377,6 +393,7 @@ __device__ __forceinline__ bool shade(const Scene* __restrict__ sc, const Hit& h
     return false;
 }
 
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -384,79 +401,191 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// render_tiles_kernel: grid = tiles owned by this ctx, block = one wavefront.
+// render_tiles_kernel<KIND, COUNT>: grid = tiles owned by this ctx, block = one wavefront (lane = frame).
 // slab layout: float4 [tileLocal][pixel 0..255][sample 0..S), S = frames*passes, sample = frame*passes + pass
+//
+// Per-lane traversal state is ONE packed reference `cur` (layout.h) + a stack pointer:
+//     cur == 0 (done)      -> the lane's ray has its nearest hit: SHADE phase (shade, or end the path, write the
+//                             sample and generate the next pixel's primary ray), then back to the root
+//     TLAS interior / leaf -> TLAS phase (two-level scenes only): slab-test two TLAS children / enter a BLAS
+//     BVH interior         -> NODE phase: fetch one 64-byte NodePair, two slab tests, ordered descend / push / pop
+//     BVH leaf             -> TRI phase: ONE Möller–Trumbore test, then the next triangle of the leaf or pop
+// Each trip of the loop counts the lanes in every state with __ballot + popcount and runs the phase with the most
+// lanes (SHADE only once kShadeBatch lanes wait or nothing else can run), so divergent rays cost their own length,
+// not the longest ray in the wave.
 // ------------------------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__(64) void render_tiles_kernel(const Scene* __restrict__ sc, float4* __restrict__ slab,
-                                                           Counters* __restrict__ counters,
+constexpr int kShadeBatch = 12;
+
+template <int KIND, bool COUNT>
+__global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4* __restrict__ slab,
+                                                           Counters* __restrict__ counters, unsigned long long* __restrict__ tileClocks,
                                                            uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                            uint32_t sppFirst, uint32_t frames, uint32_t passes)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    // XCD-aware order: consecutive tiles (which share BVH subtrees and texture rows) go to the same XCD's L2.
-    // blocks are dealt round-robin over the 8 XCDs, so block b lands on XCD b % 8.
+    const unsigned long long clk0 = COUNT ? wall_clock64() : 0ull;
+    // XCD-aware order: blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8); give each XCD a contiguous
+    // run of tiles so neighbouring tiles (same BVH subtrees, same texture rows) share one L2.  Speed only.
     uint32_t b = blockIdx.x, nb = gridDim.x;
-    uint32_t per = (nb + 7u) / 8u;
-    uint32_t tl = (b % 8u) * per + b / 8u;
-    if (nb % 8u != 0) tl = b;                        // bijective only when the grid is a multiple of 8
+    uint32_t tl = b;
+    if ((nb & 7u) == 0) tl = (b & 7u) * (nb >> 3) + (b >> 3);
     if (tl >= tileCount) return;
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     uint32_t* stk = lds + lane;
 
     Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
-    const bool active = lane < frames;
     const uint32_t S = frames * passes;
-    const int W = sc->W;
-    const f3 camPos = mk3(sc->camPos[0], sc->camPos[1], sc->camPos[2]);
-    const f3 TL = mk3(sc->topLeft[0], sc->topLeft[1], sc->topLeft[2]);
-    const f3 TR = mk3(sc->topRight[0], sc->topRight[1], sc->topRight[2]);
-    const f3 BL = mk3(sc->bottomLeft[0], sc->bottomLeft[1], sc->bottomLeft[2]);
+    const uint32_t items = 256u * passes;                                     // (pixel, pass) pairs in stream order
+    const f3 camPos = mk3(sc.camPos[0], sc.camPos[1], sc.camPos[2]);
+    const f3 TL = mk3(sc.topLeft[0], sc.topLeft[1], sc.topLeft[2]);
+    const f3 TR = mk3(sc.topRight[0], sc.topRight[1], sc.topRight[2]);
+    const f3 BL = mk3(sc.bottomLeft[0], sc.bottomLeft[1], sc.bottomLeft[2]);
 
-    if (active) {
-        const uint32_t spp = sppFirst + lane * passes;
-        uint32_t seed = init_seed(tx + ty * (uint32_t)W + spp * 1799u);            // renderer.cpp:120
-        const uint32_t items = 256u * passes;                                         // (pixel, pass) pairs in stream order
-        uint32_t item = 0;
-        bool needGen = true;
-        f3 O = camPos, D = camPos, rD = camPos; bool inside = false; int depth = 0;
-        f3 F0 = camPos, F1 = camPos, F2 = camPos, F3 = camPos, F4 = camPos;           // throughput factors of depths 0..4
-        while (item < items) {
-            if (needGen) {
-                const uint32_t pix = item / passes;
-                const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
-                const float jy = rnd(seed);                                           // pinned: first draw is the y jitter
-                const float jx = rnd(seed);
-                const float u = ((float)x + jx) * sc->invW, v = ((float)y + jy) * sc->invH;   // camera.h:23-30
-                const f3 P = TL + u * (TR - TL) + v * (BL - TL);
-                O = camPos; D = normalize3(P - camPos); rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
-                inside = false; depth = 0; needGen = false;
-                cn.primary++;
+    bool live = lane < frames;
+    uint32_t seed = init_seed(tx + ty * (uint32_t)sc.W + (sppFirst + lane * passes) * 1799u);   // renderer.cpp:120
+    uint32_t item = 0;
+    // world-space ray of the current path segment, its nearest hit so far, path state
+    f3 O = camPos, D = camPos, rD = camPos; bool inside = false; int depth = 0;
+    Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+    f3 F0 = camPos, F1 = camPos, F2 = camPos, F3 = camPos, F4 = camPos;    // throughput factors of depths 0..4
+    // traversal state; (tO, tD, trD) = ray in the space of the structure being walked (object space inside a BLAS)
+    uint32_t cur = kRefDone, sp = 0;
+    f3 tO = camPos, tD = camPos, trD = camPos;
+    bool fresh = true;                                                        // true: SHADE phase must generate a primary ray
+
+    for (;;) {
+        const unsigned long long mDone = __ballot(live && cur == kRefDone);
+        const unsigned long long mNode = __ballot(live && (cur & 0xC0000000u) == kRefInterior);
+        const unsigned long long mTri = __ballot(live && cur != kRefDone && (cur & 0xC0000000u) == 0u);
+        const unsigned long long mTlas = (KIND == 1) ? __ballot(live && (cur & kRefTlasBit) != 0u) : 0ull;
+        const int nDone = __popcll(mDone), nNode = __popcll(mNode), nTri = __popcll(mTri), nTlas = __popcll(mTlas);
+        const int nWalk = nNode + nTri + nTlas;
+        if (nDone + nWalk == 0) break;
+
+        if (nDone >= kShadeBatch || nWalk == 0) {
+            // ---------------- SHADE / RAY-GEN phase --------------------------------------------------------------
+            if (live && cur == kRefDone) {
+                bool gen = fresh;
+                if (!fresh) {
+                    if (h.objIdx >= 2) cn.meshhits++;
+                    f3 factor, L;
+                    const bool done = shade(sc, h, O, D, rD, inside, depth, seed, factor, L);
+                    if (!done) {
+                        if (depth == 0) F0 = factor; else if (depth == 1) F1 = factor; else if (depth == 2) F2 = factor;
+                        else if (depth == 3) F3 = factor; else F4 = factor;
+                        depth++;
+                    } else {
+                        // unwind the recursion: innermost factor first (albedo*medium*Sample(...) multiplies on return)
+                        if (depth > 4) L = F4 * L;
+                        if (depth > 3) L = F3 * L;
+                        if (depth > 2) L = F2 * L;
+                        if (depth > 1) L = F1 * L;
+                        if (depth > 0) L = F0 * L;
+                        const uint32_t pix = item / passes, pass = item - pix * passes;
+                        slab[((size_t)tl * 256u + pix) * S + (size_t)lane * passes + pass] = make_float4(L.x, L.y, L.z, 0.0f);
+                        item++;
+                        gen = true;
+                        if (item >= items) { live = false; gen = false; }
+                    }
+                }
+                if (gen) {
+                    const uint32_t pix = item / passes;
+                    const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
+                    const float jy = rnd(seed);                                       // pinned: first draw is the y jitter
+                    const float jx = rnd(seed);
+                    const float u = ((float)x + jx) * sc.invW, v = ((float)y + jy) * sc.invH;   // camera.h:23-30
+                    const f3 P = TL + u * (TR - TL) + v * (BL - TL);
+                    O = camPos; D = normalize3(P - camPos); rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
+                    inside = false; depth = 0; fresh = false;
+                    cn.primary++;
+                }
+                if (live) {
+                    // scene.FindNearest starts: light quad, floor plane, then the acceleration structure from its root
+                    cn.rays++;
+                    h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+                    hit_light_floor(sc, O, D, h);
+                    tO = O; tD = D; trD = rD;
+                    cur = sc.rootRef; sp = 0;
+                    if (COUNT && KIND == 0 && (cur & 0xC0000000u) == 0u) cn.leaf++;
+                }
             }
-            Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
-            int traversed = 0, tested = 0;
-            find_nearest<COUNT>(sc, O, D, rD, h, stk, cn, traversed, tested);
-            f3 factor, L;
-            const bool done = shade(sc, h, O, D, rD, inside, depth, seed, factor, L);
-            if (!done) {
-                if (depth == 0) F0 = factor; else if (depth == 1) F1 = factor; else if (depth == 2) F2 = factor;
-                else if (depth == 3) F3 = factor; else F4 = factor;
-                depth++;
-            } else {
-                // unwind the recursion: innermost factor first (albedo*medium*Sample(...) multiplies on return)
-                if (depth > 4) L = F4 * L;
-                if (depth > 3) L = F3 * L;
-                if (depth > 2) L = F2 * L;
-                if (depth > 1) L = F1 * L;
-                if (depth > 0) L = F0 * L;
-                const uint32_t pix = item / passes, pass = item - pix * passes;
-                slab[((size_t)tl * 256u + pix) * S + (size_t)lane * passes + pass] = make_float4(L.x, L.y, L.z, 0.0f);
-                item++;
-                needGen = true;
+        } else if (KIND == 1 && nTlas >= nNode && nTlas >= nTri) {
+            // ---------------- TLAS phase (infra/tlas_bvh.cpp:83-111) -------------------------------------------------
+            if (live && (cur & kRefTlasBit) != 0u) {
+                if (COUNT) cn.tlas++;
+                uint32_t next;
+                if ((cur & kRefInterior) != 0u) {
+                    // TLAS leaf: enter the BLAS (BLASBVH::Intersect): object-space ray, marker on the stack, BLAS root
+                    if (COUNT) cn.visits++;
+                    const Instance* in = sc.inst + (cur & 0xffffu);
+                    to_object_space(in, O, D, tO, tD, trD);
+                    stk[sp * 64] = kRefReturn; sp++;
+                    next = in->rootRef;
+                } else {
+                    const char* p1 = reinterpret_cast<const char*>(sc.tlas + (cur & 0x7fffu));
+                    const char* p2 = reinterpret_cast<const char*>(sc.tlas + ((cur >> 15) & 0x7fffu));
+                    const float4 alo = ld4(p1), ahi = ld4(p1 + 16), blo = ld4(p2), bhi = ld4(p2 + 16);
+                    float d1 = box_exact(alo, ahi, tO, trD, h.t), d2 = box_exact(blo, bhi, tO, trD, h.t);
+                    uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
+                    if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+                    if (d1 == 1e30f) next = sp ? stk[(--sp) * 64] : kRefDone;
+                    else { next = r1; if (d2 != 1e30f) { stk[sp * 64] = r2; sp++; } }
+                }
+                if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+                cur = next;
+            }
+        } else if (nNode >= nTri) {
+            // ---------------- NODE phase (infra/bvh.cpp:244-257) -------------------------------------------------
+            const bool mine = live && (cur & 0xC0000000u) == kRefInterior;
+            const bool allFinite = __ballot(mine && !finite3(trD)) == 0ull;
+            if (mine) {
+                if (COUNT) cn.interior++;
+                const char* p = reinterpret_cast<const char*>(sc.pairs + (cur & 0x3fffffffu));
+                const float4 alo = ld4(p), ahi = ld4(p + 16), blo = ld4(p + 32), bhi = ld4(p + 48);
+                float d1, d2;
+                if (allFinite) { d1 = box_fast(alo, ahi, tO, trD, h.t); d2 = box_fast(blo, bhi, tO, trD, h.t); }
+                else { d1 = box_exact(alo, ahi, tO, trD, h.t); d2 = box_exact(blo, bhi, tO, trD, h.t); }
+                uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
+                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+                uint32_t next;
+                if (d1 == 1e30f) {
+                    next = sp ? stk[(--sp) * 64] : kRefDone;
+                    if (KIND == 1 && next == kRefReturn) {                           // BLAS finished: back to the world-space ray
+                        tO = O; tD = D; trD = rD;
+                        next = sp ? stk[(--sp) * 64] : kRefDone;
+                    }
+                } else {
+                    next = r1;
+                    if (d2 != 1e30f) { stk[sp * 64] = r2; sp++; }
+                }
+                if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+                cur = next;
+            }
+        } else {
+            // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:232-243) --------------------
+            if (live && cur != kRefDone && (cur & 0xC0000000u) == 0u) {
+                if (COUNT) cn.tri++;
+                hit_tri(sc.leaf, cur & 0xffffffu, tO, tD, h);
+                uint32_t next;
+                if ((cur >> 24) > 1u) next = cur - 0x01000000u + 1u;                 // count - 1, slot + 1
+                else {
+                    next = sp ? stk[(--sp) * 64] : kRefDone;
+                    if (KIND == 1 && next == kRefReturn) {
+                        tO = O; tD = D; trD = rD;
+                        next = sp ? stk[(--sp) * 64] : kRefDone;
+                    }
+                    if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+                }
+                cur = next;
             }
         }
+    }
+
+    if (COUNT && tileClocks && lane == 0) {                 // instrumentation build only: per-tile wall time + start stamp
+        tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
+        tileClocks[2 * tl + 1] = clk0;
     }
     // wave-level reduction of the counters, one atomic per counter per wave
     uint32_t vals[8] = {cn.rays, cn.primary, cn.interior, cn.leaf, cn.tri, cn.tlas, cn.visits, cn.meshhits};
@@ -491,12 +620,12 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// find_nearest_kernel: one ray per lane
+// find_nearest_kernel: one ray per lane, reference traversal order (reports Ray::traversed / tested)
 // ------------------------------------------------------------------------------------------------------------
 struct RayIn { float O[3]; float D[3]; int32_t inside; };
 struct HitOut { float t, u, v; int32_t objIdx, triIdx, traversed, tested; };
 
-__global__ __launch_bounds__(64) void find_nearest_kernel(const Scene* __restrict__ sc, const RayIn* __restrict__ rays,
+__global__ __launch_bounds__(64) void find_nearest_kernel(const Scene sc, const RayIn* __restrict__ rays,
                                                            HitOut* __restrict__ hits, uint32_t n, Counters* __restrict__ counters)
 {
     extern __shared__ uint32_t lds[];
@@ -509,7 +638,7 @@ __global__ __launch_bounds__(64) void find_nearest_kernel(const Scene* __restric
         f3 rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);                                       // Ray ctor, template/ray.h:15-24
         Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
         int traversed = 0, tested = 0;
-        find_nearest<true>(sc, O, D, rD, h, lds + lane, cn, traversed, tested);
+        find_nearest_seq(sc, O, D, rD, h, lds + lane, cn, traversed, tested);
         HitOut o; o.t = h.t; o.u = h.u; o.v = h.v; o.objIdx = h.objIdx; o.triIdx = h.triIdx; o.traversed = traversed; o.tested = tested;
         hits[i] = o;
     }
@@ -550,16 +679,16 @@ __global__ __launch_bounds__(64) void resolve_kernel(const float4* __restrict__ 
 // ------------------------------------------------------------------------------------------------------------
 // launch wrappers (called from abi.cpp)
 // ------------------------------------------------------------------------------------------------------------
-extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, uint32_t tileFirst, uint32_t tileStride,
-                                        uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst, uint32_t frames, uint32_t passes,
-                                        uint32_t ldsBytes, int collectStats, hipStream_t stream)
+extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks,
+                                        uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
+                                        uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
     dim3 grid(tileCount), block(64);
-    if (collectStats)
-        hipLaunchKernelGGL(crt::render_tiles_kernel<true>, grid, block, ldsBytes, stream, sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes);
-    else
-        hipLaunchKernelGGL(crt::render_tiles_kernel<false>, grid, block, ldsBytes, stream, sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes);
+#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileClocks, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes)
+    if (sc->kind == 0) { if (collectStats) CRT_LAUNCH(0, true); else CRT_LAUNCH(0, false); }
+    else { if (collectStats) CRT_LAUNCH(1, true); else CRT_LAUNCH(1, false); }
+#undef CRT_LAUNCH
     return hipGetLastError();
 }
 
@@ -577,7 +706,7 @@ extern "C" hipError_t crt_launch_find_nearest(const crt::Scene* sc, const void* 
 {
     if (n == 0) return hipSuccess;
     dim3 grid((n + 63u) / 64u), block(64);
-    hipLaunchKernelGGL(crt::find_nearest_kernel, grid, block, ldsBytes, stream, sc, (const crt::RayIn*)rays, (crt::HitOut*)hits, n, counters);
+    hipLaunchKernelGGL(crt::find_nearest_kernel, grid, block, ldsBytes, stream, *sc, (const crt::RayIn*)rays, (crt::HitOut*)hits, n, counters);
     return hipGetLastError();
 }
 

@@ -11,12 +11,21 @@
 
 namespace crt {
 
-// packed node reference carried on the traversal stack (32 bit)
-//   interior : bit31 = 1, bits 0..30 = NodePair index  ((leftFirst - 1) / 2)
-//   leaf     : bit31 = 0, bits 24..30 = triCount (1..127), bits 0..23 = first leaf-triangle slot
-constexpr uint32_t kInteriorFlag = 0x80000000u;
-constexpr uint32_t kMaxLeafTris = 127u;
+// packed node reference carried in registers / on the traversal stack (32 bit); all indices are GLOBAL (the
+// uploader folds each BLAS's array bases in), so a reference alone identifies the record to fetch.
+//   bits 31..30 = 10 : BVH / BLAS interior, bits 0..29 = NodePair index
+//   bits 31..30 = 00 : BVH / BLAS leaf,     bits 24..29 = triCount (1..63), bits 0..23 = first LeafTri slot;  0 = "traversal done"
+//   bits 31..30 = 01 : TLAS interior,       bits 0..14 = left child TlasNode index, bits 15..29 = right child
+//   bits 31..30 = 11 : TLAS leaf,           bits 0..15 = BLAS (Instance) index;  0xFFFFFFFF = "return to TLAS level" stack marker
+constexpr uint32_t kRefInterior = 0x80000000u;
+constexpr uint32_t kRefTlasBit = 0x40000000u;
+constexpr uint32_t kRefTlasInterior = 0x40000000u;
+constexpr uint32_t kRefTlasLeaf = 0xC0000000u;
+constexpr uint32_t kRefReturn = 0xFFFFFFFFu;
+constexpr uint32_t kRefDone = 0u;
+constexpr uint32_t kMaxLeafTris = 63u;
 constexpr uint32_t kMaxLeafSlots = 1u << 24;
+constexpr uint32_t kMaxPairs = 1u << 30;
 
 struct alignas(16) NodeChild { float lo[3]; uint32_t ref; float hi[3]; uint32_t pad; };   // 32 B
 struct alignas(64) NodePair { NodeChild c[2]; };                                           // 64 B
@@ -33,16 +42,16 @@ struct alignas(16) ShadeTri {             // 64 B
     int32_t objIdx;
 };
 
-struct alignas(16) TlasNode { float lo[3]; uint32_t leftRight; float hi[3]; uint32_t blas; }; // 32 B
+struct alignas(16) TlasNode { float lo[3]; uint32_t ref; float hi[3]; uint32_t pad; };         // 32 B; ref = packed reference of THIS node
 
 struct alignas(16) Instance {             // 128 B
     float invT[12];                       // rows 0..2 of BLASBVH::invT (ray -> object space)
     float T[12];                          // rows 0..2 of BLASBVH::T    (normal -> world space)
-    uint32_t pairBase, leafBase, shadeBase;
+    uint32_t shadeBase;
     int32_t matIdx;
-    uint32_t rootRef;                     // packed reference of node 0
+    uint32_t rootRef;                     // packed (global) reference of the BLAS's node 0
     int32_t objIdx;
-    uint32_t pad[2];
+    uint32_t pad[4];
 };
 
 struct alignas(16) Material {             // 32 B
@@ -55,7 +64,7 @@ struct alignas(16) Material {             // 32 B
 
 struct TexDesc { uint32_t offset; int32_t w, h; uint32_t pad; };   // offset in texels into the texel pool
 
-struct Scene {                            // lives in device memory; read through scalar loads
+struct Scene {                            // passed to the kernels BY VALUE (kernel argument segment -> scalar loads, global pointers)
     int32_t kind;                         // 0 FileScene, 1 TLASFileScene
     int32_t depthLimit;
     // camera (template/camera.h)
@@ -71,10 +80,10 @@ struct Scene {                            // lives in device memory; read throug
     const Material* mats;
     const NodePair* pairs; const LeafTri* leaf; const ShadeTri* shade;
     const int32_t* objMat;                // FileScene: object id - 2 -> material
-    uint32_t rootRef;                     // FileScene: packed reference of node 0
+    uint32_t rootRef;                     // packed reference of the root (BVH node 0 / TLAS node 0)
     const TlasNode* tlas; const Instance* inst;
-    // traversal stack geometry (dwords per lane)
-    uint32_t bvhStack, tlasStack;
+    uint32_t stackDepth;                  // dwords per lane of the LDS traversal stack (BVH height + TLAS height + 1 marker + slack)
+    uint32_t bvhStack;                    // of which the BVH part (find_nearest_kernel keeps the TLAS entries above it)
 };
 
 struct Counters { unsigned long long v[8]; };   // order = crt_counters

@@ -158,6 +158,9 @@ int  crt_find_nearest(crt_ctx* ctx, const crt_ray* rays, crt_hit* hits, size_t n
 int  crt_get_counters(crt_ctx* ctx, crt_counters* out);        /* cumulative since create / crt_reset_counters       */
 int  crt_reset_counters(crt_ctx* ctx);
 int  crt_get_timing(crt_ctx* ctx, crt_timing* out);            /* syncs the stream                                   */
+/* collectStats contexts only: for each owned tile i of the LAST render launch, out[2i] = wall time of the tile's
+ * wavefront and out[2i+1] = its start stamp, both in ticks of the 100 MHz constant clock (load-balance map). */
+int  crt_get_tile_clocks(crt_ctx* ctx, uint64_t* out /* 2 * tileCount */);
 
 /* ---- multi-GPU plumbing ---------------------------------------------------------------------------------
  * The accumulator can live in caller-owned device memory (e.g. a torch tensor that torch.distributed/RCCL
