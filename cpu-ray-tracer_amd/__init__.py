@@ -17,7 +17,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libcrt_amd.so")
+LIB_PATH = os.environ.get("CRT_LIB_PATH") or os.path.join(HERE, "libcrt_amd.so")   # CRT_LIB_PATH: A/B builds of the same library (tools/ab_bench.py)
 
 SCENE_FILE, SCENE_TLAS = 0, 1
 

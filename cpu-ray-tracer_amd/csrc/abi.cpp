@@ -177,8 +177,8 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     if ((e = hipMalloc((void**)&c->dCounters, sizeof(crt::Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemsetAsync(c->dCounters, 0, sizeof(crt::Counters), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
     if (c->cfg.collectStats && count > 0) {
-        if ((e = hipMalloc((void**)&c->dTileClocks, (size_t)count * 16)) != hipSuccess) return bail(e, "hipMalloc(tileClocks)");
-        if ((e = hipMemsetAsync(c->dTileClocks, 0, (size_t)count * 16, c->stream)) != hipSuccess) return bail(e, "hipMemset(tileClocks)");
+        if ((e = hipMalloc((void**)&c->dTileClocks, (size_t)count * 96)) != hipSuccess) return bail(e, "hipMalloc(tileClocks)");
+        if ((e = hipMemsetAsync(c->dTileClocks, 0, (size_t)count * 96, c->stream)) != hipSuccess) return bail(e, "hipMemset(tileClocks)");
     }
     // Camera() defaults, template/camera.h:14-22
     memset(&c->hScene, 0, sizeof(c->hScene));
@@ -348,6 +348,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     if ((r = upload(c, tex, &s.tex))) return r;
     if ((r = upload(c, mats, &s.mats))) return r;
     if ((r = upload(c, pairs, &s.pairs))) return r;
+    { crt::LeafTri padRec; memset(&padRec, 0, sizeof(padRec)); leaf.push_back(padRec); }   // record fetches read 64 B from a 48-B LeafTri
     if ((r = upload(c, leaf, &s.leaf))) return r;
     if ((r = upload(c, shade, &s.shade))) return r;
     if ((r = upload(c, objMat, &s.objMat))) return r;
@@ -511,6 +512,16 @@ int crt_get_tile_clocks(crt_ctx* c, uint64_t* out)
     if (!c->dTileClocks) return c->fail(CRT_ERR_STATE, "tile clocks are recorded only by a collectStats context");
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipMemcpyAsync(out, c->dTileClocks, (size_t)c->tileCount * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+// diagnostic builds (-DCRT_STAMPS) only: 10 extra words per tile behind the tile clocks (not part of the public ABI)
+extern "C" int crt_debug_tile_stamps(crt_ctx* c, uint64_t* out)
+{
+    if (!c || !out || !c->dTileClocks) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipMemcpyAsync(out, c->dTileClocks + 2 * (size_t)c->tileCount, (size_t)c->tileCount * 80, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
 }

@@ -404,17 +404,25 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // render_tiles_kernel<KIND, COUNT>: grid = tiles owned by this ctx, block = one wavefront (lane = frame).
 // slab layout: float4 [tileLocal][pixel 0..255][sample 0..S), S = frames*passes, sample = frame*passes + pass
 //
-// Per-lane traversal state is ONE packed reference `cur` (layout.h) + a stack pointer:
-//     cur == 0 (done)      -> the lane's ray has its nearest hit: SHADE phase (shade, or end the path, write the
-//                             sample and generate the next pixel's primary ray), then back to the root
-//     TLAS interior / leaf -> TLAS phase (two-level scenes only): slab-test two TLAS children / enter a BLAS
-//     BVH interior         -> NODE phase: fetch one 64-byte NodePair, two slab tests, ordered descend / push / pop
-//     BVH leaf             -> TRI phase: ONE Möller–Trumbore test, then the next triangle of the leaf or pop
-// Each trip of the loop counts the lanes in every state with __ballot + popcount and runs the phase with the most
-// lanes (SHADE only once kShadeBatch lanes wait or nothing else can run), so divergent rays cost their own length,
-// not the longest ray in the wave.
+// Per-lane traversal state is ONE packed reference `cur` (layout.h), the 64-byte record it names — already
+// PRE-LOADED into registers q0..q3 by the trip that produced it — and a stack whose top lives in a register:
+//     cur == 0 (done)      -> SHADE phase: shade the hit (or end the path: unwind, write the sample, generate the next
+//                             pixel's primary ray), start FindNearest for the new ray (quad, plane), cur = root
+//     BVH interior         -> NODE phase: two slab tests on the pre-loaded NodePair, ordered descend / push / pop
+//     BVH leaf             -> TRI phase: ONE Möller–Trumbore test on the pre-loaded LeafTri, next triangle or pop
+//     TLAS interior / leaf -> TLAS phase (two-level scenes): two slab tests on the pre-loaded child nodes / enter the
+//                             BLAS through the pre-loaded invT rows
+// One trip of the wave's loop = ballot the states, run each phase that has enough lanes (thresholds below; a phase
+// always runs when nothing else can), then issue the record loads for every lane that moved.  The loads fly while
+// the next trip's ballots and the other phases' arithmetic execute, so the dependent-fetch latency of the pointer
+// chase is overlapped even when the wave is alone on its SIMD, and a lane only ever pays for its own ray's length.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kShadeBatch = 12;
+#ifndef CRT_SHADE_BATCH
+#define CRT_SHADE_BATCH 24
+#endif
+#ifndef CRT_TRI_BATCH
+#define CRT_TRI_BATCH 1
+#endif
 
 template <int KIND, bool COUNT>
 __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4* __restrict__ slab,
@@ -436,6 +444,14 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
     uint32_t* stk = lds + lane;
 
     Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
+    uint32_t trips = 0;
+#ifdef CRT_STAMPS
+    // diagnostic build (-DCRT_STAMPS): shader-clock time per phase of this wave; never compiled into the product
+    unsigned long long stT[6] = {0, 0, 0, 0, 0, 0}; uint32_t stN[4] = {0, 0, 0, 0};
+#define CRT_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define CRT_STAMP(var)
+#endif
     const uint32_t S = frames * passes;
     const uint32_t items = 256u * passes;                                     // (pixel, pass) pairs in stream order
     const f3 camPos = mk3(sc.camPos[0], sc.camPos[1], sc.camPos[2]);
@@ -451,141 +467,196 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
     Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
     f3 F0 = camPos, F1 = camPos, F2 = camPos, F3 = camPos, F4 = camPos;    // throughput factors of depths 0..4
     // traversal state; (tO, tD, trD) = ray in the space of the structure being walked (object space inside a BLAS)
-    uint32_t cur = kRefDone, sp = 0;
+    uint32_t cur = kRefDone, sp = 0, tos = 0;                                 // sp counts entries including the register-held top
     f3 tO = camPos, tD = camPos, trD = camPos;
+    bool rayFinite = true;                                                    // all of trD finite -> v_min/v_max slab test is exact
     bool fresh = true;                                                        // true: SHADE phase must generate a primary ray
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;           // pre-loaded record of `cur`
+
+#define CRT_PUSH(x) do { if (sp) stk[(sp - 1u) * 64u] = tos; tos = (x); sp++; } while (0)
+#define CRT_POP(dst) do { if (sp) { (dst) = tos; sp--; if (sp) tos = stk[(sp - 1u) * 64u]; } else (dst) = kRefDone; } while (0)
+    // pop for the BVH phases: the return marker switches back to the world-space ray and pops the TLAS entry below it
+#define CRT_POP_BVH(dst) do { CRT_POP(dst); if (KIND == 1 && (dst) == kRefReturn) { tO = O; tD = D; trD = rD; rayFinite = finite3(rD); CRT_POP(dst); } } while (0)
 
     for (;;) {
-        const unsigned long long mDone = __ballot(live && cur == kRefDone);
-        const unsigned long long mNode = __ballot(live && (cur & 0xC0000000u) == kRefInterior);
-        const unsigned long long mTri = __ballot(live && cur != kRefDone && (cur & 0xC0000000u) == 0u);
-        const unsigned long long mTlas = (KIND == 1) ? __ballot(live && (cur & kRefTlasBit) != 0u) : 0ull;
-        const int nDone = __popcll(mDone), nNode = __popcll(mNode), nTri = __popcll(mTri), nTlas = __popcll(mTlas);
-        const int nWalk = nNode + nTri + nTlas;
-        if (nDone + nWalk == 0) break;
+        const bool isDone = live && cur == kRefDone;
+        const bool isNode = live && (cur & 0xC0000000u) == kRefInterior;
+        const bool isTri = live && cur != kRefDone && (cur & 0xC0000000u) == 0u;
+        const bool isTlas = (KIND == 1) && live && (cur & kRefTlasBit) != 0u;
+        const int nDone = __popcll(__ballot(isDone)), nNode = __popcll(__ballot(isNode)), nTri = __popcll(__ballot(isTri));
+        const int nTlas = (KIND == 1) ? __popcll(__ballot(isTlas)) : 0;
+        if (nDone + nNode + nTri + nTlas == 0) break;
+        if (COUNT) trips++;
+        const bool runNode = nNode > 0;
+        const bool runTlas = nTlas > 0;
+        const bool runTri = nTri >= CRT_TRI_BATCH || (nTri > 0 && nNode + nTlas == 0);
+        const bool runShade = nDone >= CRT_SHADE_BATCH || (nDone > 0 && !runNode && !runTlas && !runTri);
+        bool moved = false;
+#ifdef CRT_STAMPS
+        CRT_STAMP(s0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CRT_STAMP(s1);
+        stT[0] += s1 - s0;
+        if (runShade) stN[0]++; if (runNode) stN[1]++; if (runTri) stN[2]++;
+#endif
 
-        if (nDone >= kShadeBatch || nWalk == 0) {
+        if (runShade && isDone) {
             // ---------------- SHADE / RAY-GEN phase --------------------------------------------------------------
-            if (live && cur == kRefDone) {
-                bool gen = fresh;
-                if (!fresh) {
-                    if (h.objIdx >= 2) cn.meshhits++;
-                    f3 factor, L;
-                    const bool done = shade(sc, h, O, D, rD, inside, depth, seed, factor, L);
-                    if (!done) {
-                        if (depth == 0) F0 = factor; else if (depth == 1) F1 = factor; else if (depth == 2) F2 = factor;
-                        else if (depth == 3) F3 = factor; else F4 = factor;
-                        depth++;
-                    } else {
-                        // unwind the recursion: innermost factor first (albedo*medium*Sample(...) multiplies on return)
-                        if (depth > 4) L = F4 * L;
-                        if (depth > 3) L = F3 * L;
-                        if (depth > 2) L = F2 * L;
-                        if (depth > 1) L = F1 * L;
-                        if (depth > 0) L = F0 * L;
-                        const uint32_t pix = item / passes, pass = item - pix * passes;
-                        slab[((size_t)tl * 256u + pix) * S + (size_t)lane * passes + pass] = make_float4(L.x, L.y, L.z, 0.0f);
-                        item++;
-                        gen = true;
-                        if (item >= items) { live = false; gen = false; }
-                    }
-                }
-                if (gen) {
-                    const uint32_t pix = item / passes;
-                    const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
-                    const float jy = rnd(seed);                                       // pinned: first draw is the y jitter
-                    const float jx = rnd(seed);
-                    const float u = ((float)x + jx) * sc.invW, v = ((float)y + jy) * sc.invH;   // camera.h:23-30
-                    const f3 P = TL + u * (TR - TL) + v * (BL - TL);
-                    O = camPos; D = normalize3(P - camPos); rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
-                    inside = false; depth = 0; fresh = false;
-                    cn.primary++;
-                }
-                if (live) {
-                    // scene.FindNearest starts: light quad, floor plane, then the acceleration structure from its root
-                    cn.rays++;
-                    h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
-                    hit_light_floor(sc, O, D, h);
-                    tO = O; tD = D; trD = rD;
-                    cur = sc.rootRef; sp = 0;
-                    if (COUNT && KIND == 0 && (cur & 0xC0000000u) == 0u) cn.leaf++;
-                }
-            }
-        } else if (KIND == 1 && nTlas >= nNode && nTlas >= nTri) {
-            // ---------------- TLAS phase (infra/tlas_bvh.cpp:83-111) -------------------------------------------------
-            if (live && (cur & kRefTlasBit) != 0u) {
-                if (COUNT) cn.tlas++;
-                uint32_t next;
-                if ((cur & kRefInterior) != 0u) {
-                    // TLAS leaf: enter the BLAS (BLASBVH::Intersect): object-space ray, marker on the stack, BLAS root
-                    if (COUNT) cn.visits++;
-                    const Instance* in = sc.inst + (cur & 0xffffu);
-                    to_object_space(in, O, D, tO, tD, trD);
-                    stk[sp * 64] = kRefReturn; sp++;
-                    next = in->rootRef;
+            bool gen = fresh;
+            if (!fresh) {
+                if (h.objIdx >= 2) cn.meshhits++;
+                f3 factor, L;
+                const bool done = shade(sc, h, O, D, rD, inside, depth, seed, factor, L);
+                if (!done) {
+                    if (depth == 0) F0 = factor; else if (depth == 1) F1 = factor; else if (depth == 2) F2 = factor;
+                    else if (depth == 3) F3 = factor; else F4 = factor;
+                    depth++;
                 } else {
-                    const char* p1 = reinterpret_cast<const char*>(sc.tlas + (cur & 0x7fffu));
-                    const char* p2 = reinterpret_cast<const char*>(sc.tlas + ((cur >> 15) & 0x7fffu));
-                    const float4 alo = ld4(p1), ahi = ld4(p1 + 16), blo = ld4(p2), bhi = ld4(p2 + 16);
-                    float d1 = box_exact(alo, ahi, tO, trD, h.t), d2 = box_exact(blo, bhi, tO, trD, h.t);
-                    uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
-                    if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
-                    if (d1 == 1e30f) next = sp ? stk[(--sp) * 64] : kRefDone;
-                    else { next = r1; if (d2 != 1e30f) { stk[sp * 64] = r2; sp++; } }
+                    // unwind the recursion: innermost factor first (albedo*medium*Sample(...) multiplies on return)
+                    if (depth > 4) L = F4 * L;
+                    if (depth > 3) L = F3 * L;
+                    if (depth > 2) L = F2 * L;
+                    if (depth > 1) L = F1 * L;
+                    if (depth > 0) L = F0 * L;
+                    const uint32_t pix = item / passes, pass = item - pix * passes;
+                    slab[((size_t)tl * 256u + pix) * S + (size_t)lane * passes + pass] = make_float4(L.x, L.y, L.z, 0.0f);
+                    item++;
+                    gen = true;
+                    if (item >= items) { live = false; gen = false; }
                 }
-                if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
-                cur = next;
             }
-        } else if (nNode >= nTri) {
-            // ---------------- NODE phase (infra/bvh.cpp:244-257) -------------------------------------------------
-            const bool mine = live && (cur & 0xC0000000u) == kRefInterior;
-            const bool allFinite = __ballot(mine && !finite3(trD)) == 0ull;
-            if (mine) {
-                if (COUNT) cn.interior++;
-                const char* p = reinterpret_cast<const char*>(sc.pairs + (cur & 0x3fffffffu));
-                const float4 alo = ld4(p), ahi = ld4(p + 16), blo = ld4(p + 32), bhi = ld4(p + 48);
-                float d1, d2;
-                if (allFinite) { d1 = box_fast(alo, ahi, tO, trD, h.t); d2 = box_fast(blo, bhi, tO, trD, h.t); }
-                else { d1 = box_exact(alo, ahi, tO, trD, h.t); d2 = box_exact(blo, bhi, tO, trD, h.t); }
-                uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
-                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
-                uint32_t next;
-                if (d1 == 1e30f) {
-                    next = sp ? stk[(--sp) * 64] : kRefDone;
-                    if (KIND == 1 && next == kRefReturn) {                           // BLAS finished: back to the world-space ray
-                        tO = O; tD = D; trD = rD;
-                        next = sp ? stk[(--sp) * 64] : kRefDone;
-                    }
-                } else {
-                    next = r1;
-                    if (d2 != 1e30f) { stk[sp * 64] = r2; sp++; }
-                }
-                if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
-                cur = next;
+            if (gen) {
+                const uint32_t pix = item / passes;
+                const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
+                const float jy = rnd(seed);                                       // pinned: first draw is the y jitter
+                const float jx = rnd(seed);
+                const float u = ((float)x + jx) * sc.invW, v = ((float)y + jy) * sc.invH;   // camera.h:23-30
+                const f3 P = TL + u * (TR - TL) + v * (BL - TL);
+                O = camPos; D = normalize3(P - camPos); rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
+                inside = false; depth = 0; fresh = false;
+                cn.primary++;
             }
-        } else {
-            // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:232-243) --------------------
-            if (live && cur != kRefDone && (cur & 0xC0000000u) == 0u) {
-                if (COUNT) cn.tri++;
-                hit_tri(sc.leaf, cur & 0xffffffu, tO, tD, h);
-                uint32_t next;
-                if ((cur >> 24) > 1u) next = cur - 0x01000000u + 1u;                 // count - 1, slot + 1
-                else {
-                    next = sp ? stk[(--sp) * 64] : kRefDone;
-                    if (KIND == 1 && next == kRefReturn) {
-                        tO = O; tD = D; trD = rD;
-                        next = sp ? stk[(--sp) * 64] : kRefDone;
-                    }
-                    if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
-                }
-                cur = next;
+            if (live) {
+                // scene.FindNearest starts: light quad, floor plane, then the acceleration structure from its root
+                cn.rays++;
+                h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+                hit_light_floor(sc, O, D, h);
+                tO = O; tD = D; trD = rD; rayFinite = finite3(rD);
+                cur = sc.rootRef; sp = 0; moved = true;
+                if (COUNT && KIND == 0 && (cur & 0xC0000000u) == 0u) cn.leaf++;
             }
         }
+#ifdef CRT_STAMPS
+        CRT_STAMP(s2); stT[1] += s2 - s1;
+#endif
+        if (KIND == 1 && runTlas && isTlas) {
+            // ---------------- TLAS phase (infra/tlas_bvh.cpp:83-111) -------------------------------------------------
+            if (COUNT) cn.tlas++;
+            uint32_t next;
+            if ((cur & kRefInterior) != 0u) {
+                // TLAS leaf: enter the BLAS (BLASBVH::Intersect, blas_bvh.cpp:376-381): object-space ray through the
+                // pre-loaded invT rows (SSE summation order), return marker on the stack, BLAS root
+                if (COUNT) cn.visits++;
+                const f3 Oo = mk3((O.x * q0.x + O.y * q0.y) + (O.z * q0.z + 1.0f * q0.w),
+                                  (O.x * q1.x + O.y * q1.y) + (O.z * q1.z + 1.0f * q1.w),
+                                  (O.x * q2.x + O.y * q2.y) + (O.z * q2.z + 1.0f * q2.w));
+                const f3 Do = mk3((D.x * q0.x + D.y * q0.y) + D.z * q0.z,
+                                  (D.x * q1.x + D.y * q1.y) + D.z * q1.z,
+                                  (D.x * q2.x + D.y * q2.y) + D.z * q2.z);
+                tO = Oo; tD = Do; trD = mk3(1 / Do.x, 1 / Do.y, 1 / Do.z); rayFinite = finite3(trD);
+                CRT_PUSH(kRefReturn);
+                next = asu(q3.z);                                                 // Instance::rootRef
+            } else {
+                float d1 = box_exact(q0, q1, tO, trD, h.t), d2 = box_exact(q2, q3, tO, trD, h.t);
+                uint32_t r1 = asu(q0.w), r2 = asu(q2.w);
+                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+                if (d1 == 1e30f) CRT_POP(next);
+                else { next = r1; if (d2 != 1e30f) CRT_PUSH(r2); }
+            }
+            if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+            cur = next; moved = true;
+        }
+#ifdef CRT_STAMPS
+        CRT_STAMP(s3);
+#endif
+        if (runNode) {
+            // ---------------- NODE phase (infra/bvh.cpp:244-257) -------------------------------------------------
+            const bool allFinite = __ballot(isNode && !rayFinite) == 0ull;
+            if (isNode) {
+                if (COUNT) cn.interior++;
+                float d1, d2;
+                if (allFinite) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
+                else { d1 = box_exact(q0, q1, tO, trD, h.t); d2 = box_exact(q2, q3, tO, trD, h.t); }
+                uint32_t r1 = asu(q0.w), r2 = asu(q2.w);
+                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+                uint32_t next;
+                if (d1 == 1e30f) CRT_POP_BVH(next);
+                else { next = r1; if (d2 != 1e30f) CRT_PUSH(r2); }
+                if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+                cur = next; moved = true;
+            }
+        }
+#ifdef CRT_STAMPS
+        CRT_STAMP(s4); stT[2] += s4 - s3;
+#endif
+        if (runTri && isTri) {
+            // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:203-222, 232-243) -----------
+            if (COUNT) cn.tri++;
+            {
+                const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+                const f3 hh = cross3(tD, e2);
+                const float det = dot3(e1, hh);
+                const float f = 1 / det;
+                const f3 s = tO - v0;
+                const float u = f * dot3(s, hh);
+                const f3 q = cross3(s, e1);
+                const float v = f * dot3(tD, q);
+                const float t = f * dot3(e2, q);
+                const bool ok = !(det > -0.0001f && det < 0.0001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1) && (t > 0.0001f) && (t < h.t);
+                if (ok) { h.t = t; h.u = u; h.v = v; h.triIdx = (int)asu(q0.w); h.objIdx = (int)asu(q1.w); }
+            }
+            uint32_t next;
+            if ((cur >> 24) > 1u) next = cur - 0x01000000u + 1u;                     // count - 1, slot + 1
+            else {
+                CRT_POP_BVH(next);
+                if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+            }
+            cur = next; moved = true;
+        }
+#ifdef CRT_STAMPS
+        CRT_STAMP(s5); stT[3] += s5 - s4;
+#endif
+        // ---------------- issue the record loads of every lane that moved (consumed by a later trip) ---------------
+        if (moved && live && cur != kRefDone) {
+            const char* pa; const char* pb;
+            if ((cur & kRefTlasBit) == 0u) {
+                if (cur & kRefInterior) pa = reinterpret_cast<const char*>(sc.pairs + (cur & 0x3fffffffu));
+                else pa = reinterpret_cast<const char*>(sc.leaf + (cur & 0xffffffu));
+                pb = pa + 32;
+            } else if (cur & kRefInterior) {                                         // TLAS leaf: Instance {invT rows, ids}
+                pa = reinterpret_cast<const char*>(sc.inst + (cur & 0xffffu)); pb = pa + 32;
+            } else {                                                                 // TLAS interior: the two child nodes
+                pa = reinterpret_cast<const char*>(sc.tlas + (cur & 0x7fffu));
+                pb = reinterpret_cast<const char*>(sc.tlas + ((cur >> 15) & 0x7fffu));
+            }
+            q0 = ld4(pa); q1 = ld4(pa + 16); q2 = ld4(pb); q3 = ld4(pb + 16);
+        }
+#ifdef CRT_STAMPS
+        CRT_STAMP(s6); stT[4] += s6 - s5; stT[5] += s6 - s0;
+#endif
     }
+#undef CRT_PUSH
+#undef CRT_POP
+#undef CRT_POP_BVH
 
-    if (COUNT && tileClocks && lane == 0) {                 // instrumentation build only: per-tile wall time + start stamp
+    if (COUNT && tileClocks && lane == 0) {                 // instrumentation build only: per-tile wall time + loop trips
         tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
-        tileClocks[2 * tl + 1] = clk0;
+        tileClocks[2 * tl + 1] = trips;
+#ifdef CRT_STAMPS
+        unsigned long long* dbg = tileClocks + 2 * (size_t)tileCount + 10 * (size_t)tl;
+        for (int i = 0; i < 6; i++) dbg[i] = stT[i];
+        for (int i = 0; i < 4; i++) dbg[6 + i] = stN[i];
+#endif
     }
     // wave-level reduction of the counters, one atomic per counter per wave
     uint32_t vals[8] = {cn.rays, cn.primary, cn.interior, cn.leaf, cn.tri, cn.tlas, cn.visits, cn.meshhits};

@@ -44,13 +44,13 @@ struct alignas(16) ShadeTri {             // 64 B
 
 struct alignas(16) TlasNode { float lo[3]; uint32_t ref; float hi[3]; uint32_t pad; };         // 32 B; ref = packed reference of THIS node
 
-struct alignas(16) Instance {             // 128 B
+struct alignas(16) Instance {             // 128 B; the first 64 B are what entering the BLAS needs (one record fetch)
     float invT[12];                       // rows 0..2 of BLASBVH::invT (ray -> object space)
-    float T[12];                          // rows 0..2 of BLASBVH::T    (normal -> world space)
     uint32_t shadeBase;
     int32_t matIdx;
     uint32_t rootRef;                     // packed (global) reference of the BLAS's node 0
     int32_t objIdx;
+    float T[12];                          // rows 0..2 of BLASBVH::T    (normal -> world space)
     uint32_t pad[4];
 };
 

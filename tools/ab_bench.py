@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""A/B timing of kernel build variants: compiles cpu-ray-tracer_amd with extra -D flags into build/variants/
+(in the authoring container: `python tools/ab_bench.py build NAME=-DFOO=1 ...`), and times them on the GPU box
+(`python tools/ab_bench.py run`), each variant in its own process, median of the render kernel's HIP-event time."""
+import json, os, subprocess, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VDIR = os.path.join(REPO, "build", "variants")
+PKG = os.path.join(REPO, "cpu-ray-tracer_amd")
+SRC = ["csrc/device/kernels.hip", "csrc/abi.cpp", "csrc/host/accel.cpp", "csrc/host/loaders.cpp", "csrc/host/scene.cpp", "csrc/host/host_abi.cpp"]
+
+def build(specs):
+    os.makedirs(VDIR, exist_ok=True)
+    for spec in specs:
+        name, _, flags = spec.partition("=")
+        out = os.path.join(VDIR, "libcrt_%s.so" % name)
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", out] + flags.split() + SRC + ["-lz"]
+        print(" ".join(cmd)); subprocess.check_call(cmd, cwd=PKG)
+
+def run(args):
+    child = r'''
+import importlib.util, os, sys, numpy as np
+REPO = %r
+spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))
+crt = importlib.util.module_from_spec(spec); spec.loader.exec_module(crt)
+A = os.path.join(REPO, "assets")
+xml, kind, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+sc = crt.HostScene(os.path.join(A, "scenes", xml), kind, A)
+ctx = crt.Context(W, H); sc.upload(ctx)
+ts = []
+for i in range(6):
+    ctx.clear(); ctx.render(1, 64, 1); ctx.sync(); ts.append(ctx.timing()["render_kernel_ms"])
+print("%%.3f %%.3f" %% (np.median(ts[1:]), min(ts[1:])))
+''' % REPO
+    scene = args[0] if args else "bunny_scene.xml"
+    kind = args[1] if len(args) > 1 else "0"
+    W = args[2] if len(args) > 2 else "1280"
+    H = args[3] if len(args) > 3 else "720"
+    for f in sorted(os.listdir(VDIR)):
+        if not f.endswith(".so"): continue
+        env = dict(os.environ, CRT_LIB_PATH=os.path.join(VDIR, f))
+        r = subprocess.run([sys.executable, "-c", child, scene, kind, W, H], env=env, capture_output=True, text=True)
+        print("%-40s median/min kernel ms: %s %s" % (f, r.stdout.strip(), r.stderr.strip()[-200:] if r.returncode else ""))
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build": build(sys.argv[2:])
+    else: run(sys.argv[2:])

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Diagnostic (-DCRT_STAMPS build only): where the heaviest tiles' wavefronts spend their shader cycles per loop trip."""
+import ctypes as C, importlib.util, os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))
+crt = importlib.util.module_from_spec(spec); spec.loader.exec_module(crt)
+A = os.path.join(REPO, "assets")
+W, H = 1280, 720
+sc = crt.HostScene(os.path.join(A, "scenes", "bunny_scene.xml"), 0, A)
+ctx = crt.Context(W, H, collect_stats=True); sc.upload(ctx)
+ctx.render(1, 64, 1); ctx.sync(); ctx.render(1, 64, 1); ctx.sync()
+n = (W // 16) * (H // 16)
+tc = ctx.tile_clocks(n).astype(np.float64)
+st = np.zeros((n, 10), np.uint64)
+assert ctx.L.crt_debug_tile_stamps(ctx.h, st.ctypes.data_as(C.c_void_p)) == 0
+st = st.astype(np.float64)
+heavy = np.argsort(-tc[:, 0])[:32]
+names = ["wait(vmcnt)", "shade", "tlas+node", "tri", "load issue", "total"]
+trips = tc[heavy, 1].mean()
+print("32 heaviest tiles: mean wall %.0f us, trips %.0f" % (tc[heavy, 0].mean() / 100, trips))
+for i, nm in enumerate(names):
+    print("  %-12s %10.0f cycles/trip" % (nm, st[heavy, i].mean() / trips))
+print("  runs per trip: shade %.3f node %.3f tri %.3f" % tuple(st[heavy, 6 + i].mean() / trips for i in range(3)))
+print("  cycles per shade run %.0f, per tri run %.0f" % (st[heavy, 1].mean() / st[heavy, 6].mean(), st[heavy, 3].mean() / st[heavy, 8].mean()))

@@ -21,14 +21,18 @@ tm = ctx.timing()
 n = (W // 16) * (H // 16)
 tc = ctx.tile_clocks(n).astype(np.float64)
 dur = tc[:, 0] / 100.0   # us (100 MHz)
-start = (tc[:, 1] - tc[:, 1].min()) / 100.0
+trips = tc[:, 1]
 print("kernel ms", tm["render_kernel_ms"])
 print("tile wall us: min %.0f  median %.0f  mean %.0f  p90 %.0f  p99 %.0f  max %.0f" % (dur.min(), np.median(dur), dur.mean(), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
 print("sum of tile wall time / kernel time = %.1f concurrent waves on average" % (dur.sum() / (tm["render_kernel_ms"] * 1e3)))
-print("start us: median %.0f p90 %.0f max %.0f ; last end %.0f" % (np.median(start), np.percentile(start, 90), start.max(), (start + dur).max()))
+print("loop trips per tile: median %.0f mean %.0f max %.0f ; us per trip (heaviest tiles) %.3f" % (np.median(trips), trips.mean(), trips.max(), (dur[np.argsort(-dur)[:16]] / np.maximum(trips[np.argsort(-dur)[:16]], 1)).mean()))
+c = ctx.counters()
+print("counters (2 launches):", c)
+steps = (c["interior_iters"] + c["tri_tests"] + c["tlas_iters"] + c["rays"]) / 2
+print("lane-steps per launch %.3g ; wave trips per launch %.3g ; lanes advanced per trip %.1f" % (steps, trips.sum(), steps / trips.sum()))
 tw = W // 16
 m = dur.reshape(H // 16, tw)
 print("row means (us):", " ".join("%.0f" % v for v in m.mean(axis=1)))
-late = np.argsort(-(start + dur))[:8]
+late = np.argsort(-dur)[:6]
 for t in late:
-    print("  tile %d (tx %d ty %d): start %.0f dur %.0f end %.0f" % (t, t % tw, t // tw, start[t], dur[t], start[t] + dur[t]))
+    print("  tile %d (tx %d ty %d): dur %.0f us trips %.0f" % (t, t % tw, t // tw, dur[t], trips[t]))
