@@ -109,14 +109,14 @@ def main():
     scene.upload(ctx)                                             # one-time flatten + copy to HBM
     acc = torch.zeros(H, W, 4, dtype=torch.float32, device="cuda:%d" % device)
     ctx.bind_accumulator(acc.data_ptr())
-    spp_first = 1 + rank * SPP
+    spp_first = crt.spp_window(rank, SPP)
 
     def step():
         ctx.clear()
         ctx.render(spp_first, SPP, 1)
         ctx.sync()
         if dist is not None:
-            dist.all_reduce(acc)                                  # RCCL sum of the float4 accumulators over xGMI
+            crt.allreduce_accumulator(acc, dist)                  # RCCL sum of the float4 accumulators over xGMI
             torch.cuda.synchronize()
 
     # one counted pass with a statistics context (untimed) -> per-launch algorithmic bytes

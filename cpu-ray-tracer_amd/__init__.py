@@ -366,3 +366,26 @@ def load_image(path):
     a = np.ctypeslib.as_array(px, shape=(h.value, w.value)).copy()
     L.crt_host_free(C.cast(px, C.c_void_p))
     return a
+
+
+# ------------------------------------------------------------------------------------------------------------
+# multi-GPU work split (one process per GPU, torch.distributed over RCCL) — pure arithmetic, shared by bench.py and tests
+# ------------------------------------------------------------------------------------------------------------
+def spp_window(rank, frames_per_rank, first_spp=1):
+    """Weak scaling: rank r renders frames whose spp counter runs first_spp + r*F .. first_spp + (r+1)*F - 1.
+    (tile, frame) streams are independent (renderer.cpp:120), so windows can be rendered anywhere and summed."""
+    return first_spp + rank * frames_per_rank
+
+
+def tile_partition(rank, world, n_tiles):
+    """Strong scaling: rank r owns tiles r, r + world, r + 2*world, ... (interleaved: heavy image regions are shared out).
+    Returns (tileFirst, tileStride, tileCount) for crt_config.  Each pixel is non-zero on exactly one rank, so a sum
+    all-reduce of the accumulators reproduces the single-GPU image exactly."""
+    count = (n_tiles - rank + world - 1) // world if rank < n_tiles else 0
+    return rank, world, count
+
+
+def allreduce_accumulator(tensor, dist):
+    """One collective per step: sum of the float4 accumulators over all ranks (RCCL over xGMI on GPUs, gloo in CPU tests)."""
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ (run in the authoring container, where /root/reference is mounted
+and oracle/_ref — the reference's own bvh.cpp / tinyobj / stb_image compiled in place — can be built).
+
+Two kinds of vectors, named accordingly:
+  ref_*   outputs of the REAL reference code (oracle/_ref).  These pin the oracle (and, on the GPU box, the HIP path).
+  orc_*   outputs of the CPU oracle for parts of the path no executable reference exists for (integrator, camera,
+          TLAS, scene assembly): regression vectors, "parity unpinned" beyond the restatement itself.
+Fixtures are DATA (inputs + expected outputs); no reference source text is stored."""
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import orc  # noqa: E402
+
+A = os.path.join(REPO, "assets")
+RA = "/root/reference/assets"
+MESHES = ["cube", "bunny", "wok", "teapot", "japanese_torii_gate", "watch-tower", "log_fence"]
+IMAGES = ["textures/Stylized_Pavement_basecolor.png", "textures/Stylized_Wood_basecolor.tga", "textures/Defuse_wok.png"]
+
+
+def crc(a):
+    return int(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff)
+
+
+def simple_scene(mesh, kind=0, pos=(0, -1, 2), rot=(0, 180, 0), scale=(1, 1, 1)):
+    o = orc.Oracle(kind)
+    o.set_light_position((0, 3, 1))
+    o.set_floor_texture(np.full((512, 512), 0x808080, np.uint32))
+    o.set_skydome(np.full((4, 8), 0x6080c0, np.uint32))
+    o.add_material()
+    o.add_object(orc.read_obj(os.path.join(A, mesh + ".obj")), pos, rot, scale, 0)
+    o.build()
+    return o
+
+
+def main():
+    orc.build()
+    ref = orc.Ref()
+    out = {}
+    # --- ref_obj: tinyobj-resolved corners of every mesh -------------------------------------------------------
+    out["ref_obj"] = {}
+    for m in MESHES:
+        pos, nrm, uv = ref.obj_load(os.path.join(RA, m + ".obj"))
+        out["ref_obj"][m] = dict(corners=int(pos.shape[0]), pos=crc(pos), nrm=crc(nrm), uv=crc(uv))
+    # --- ref_img: stb_image decode, packed as Texture::LoadFromFile does ------------------------------------------
+    out["ref_img"] = {}
+    for f in IMAGES:
+        img = ref.image_load(os.path.join(RA, f))
+        out["ref_img"][f] = dict(shape=list(img.shape), packed=crc(orc.pack_rgb(img)))
+    # --- ref_bvh: BVH::Build of the reference on each mesh's world-space triangles --------------------------------
+    out["ref_bvh"] = {}
+    rays = {}
+    for m in MESHES:
+        o = simple_scene(m)
+        tris = o.bvh(0)["tris"]
+        h, rb = ref.bvh_build(tris)
+        out["ref_bvh"][m] = dict(tris=int(len(tris)), nodesUsed=int(rb["nodesUsed"]), maxDepth=int(rb["maxDepth"]),
+                                 nodes=crc(rb["nodes"]), triIndices=crc(rb["triIndices"]), tris_crc=crc(tris))
+        if m in ("bunny", "teapot", "cube"):
+            rng = np.random.default_rng(1234)
+            n = 3000
+            O = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+            O[:, 1] = np.abs(O[:, 1]) + 0.2
+            T = rng.uniform(-0.8, 0.8, (n, 3)).astype(np.float32) + np.array([0, -0.3, 2], np.float32)
+            D = T - O
+            D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+            hits = ref.bvh_intersect(h, O, D)
+            rays[m] = dict(O=O, D=D, t=hits["t"], u=hits["u"], v=hits["v"], objIdx=hits["objIdx"], triIdx=hits["triIdx"],
+                           traversed=hits["traversed"], tested=hits["tested"])
+        ref.bvh_free(h)
+    np.savez_compressed(os.path.join(HERE, "ref_bvh_rays.npz"), **{"%s_%s" % (m, k): v for m, d in rays.items() for k, v in d.items()})
+    # --- orc_render: oracle accumulators of the BASELINE scenes at small sizes (regression vectors) ------------------
+    out["orc_render"] = {}
+    for name, xml, kind, W, H, frames in [("bunny", "bunny_scene.xml", 0, 96, 64, 4), ("tlas", "tlas_scene.xml", 1, 96, 64, 3),
+                                          ("cube", "cube_scene.xml", 0, 64, 48, 4)]:
+        o, _ = orc.load_scene(os.path.join(A, "scenes", xml), kind, A)
+        o.renderer_init(W, H)
+        o.render(frames, 4)
+        acc = o.accumulator()
+        c = o.counters()
+        seeds = [o.tile_seed(frames, t) for t in range((W // 16) * (H // 16))]
+        np.save(os.path.join(HERE, "orc_render_%s.npy" % name), acc)
+        out["orc_render"][name] = dict(xml=xml, kind=kind, W=W, H=H, frames=frames, acc=crc(acc), counters=c,
+                                       energy=float(np.float32(o.energy())), screen=crc(o.screen()), last_frame_tile_seeds=crc(np.array(seeds, np.uint32)))
+    # --- orc_whitted: config 1 (cube, Whitted, 640x360) hash ---------------------------------------------------------
+    o, _ = orc.load_scene(os.path.join(A, "scenes", "cube_scene.xml"), 0, A)
+    o.renderer_init(640, 360)
+    o.whitted(4)
+    out["orc_whitted_cube_640x360"] = dict(acc=crc(o.accumulator()), screen=crc(o.screen()), counters=o.counters())
+    json.dump(out, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
+    print("wrote", os.path.join(HERE, "golden.json"))
+
+
+if __name__ == "__main__":
+    main()

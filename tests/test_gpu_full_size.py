@@ -1,0 +1,127 @@
+"""Full-size runs (BASELINE.json sizes) checked through size-independent properties + oracle spot checks on a few tiles."""
+import numpy as np
+import pytest
+
+from conftest import ASSETS, scene_path
+
+pytestmark = pytest.mark.gpu
+
+W, H, SPP = 1280, 720, 64
+
+
+@pytest.fixture(scope="module")
+def full(crt):
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(W, H)
+    hs.upload(ctx)
+    ctx.render(1, SPP, 1)
+    return hs, ctx, ctx.accumulator(), ctx.counters()
+
+
+def test_config2_counters_and_finiteness(full):
+    _, _, acc, c = full
+    tiles = (W // 16) * (H // 16)
+    assert c["primary"] == tiles * 256 * SPP == W * H * SPP
+    assert c["primary"] <= c["rays"] <= 6 * c["primary"]
+    assert np.isfinite(acc).all() and (acc[..., :3] >= 0).all() and not acc[..., 3].any()
+    assert acc[..., :3].max() <= 24.0 * SPP * 1.0001
+
+
+def test_config2_is_deterministic_and_tile_split_invariant(crt, full):
+    """idempotence (same launch again -> same bits) and multi-GPU style tile ownership: 3 interleaved contexts, summed, equal
+    the single-context image exactly (each pixel is non-zero in one of them)"""
+    hs, _, acc, c = full
+    ctx2 = crt.Context(W, H)
+    hs.upload(ctx2)
+    ctx2.render(1, SPP, 1)
+    assert np.array_equal(ctx2.accumulator(), acc)
+    ctx2.close()
+    tiles = (W // 16) * (H // 16)
+    total = np.zeros_like(acc)
+    rays = 0
+    for r in range(3):
+        first, stride, count = crt.tile_partition(r, 3, tiles)
+        cx = crt.Context(W, H, tile_first=first, tile_stride=stride, tile_count=count)
+        hs.upload(cx)
+        cx.render(1, SPP, 1)
+        part = cx.accumulator()
+        assert not (total.astype(bool) & part.astype(bool)).any()
+        total += part
+        rays += cx.counters()["rays"]
+        cx.close()
+    assert np.array_equal(total, acc) and rays == c["rays"]
+
+
+def test_config2_frame_window_additivity(crt, full):
+    """linearity over frames: 64 frames = (spp 1..40) then (spp 41..64) on the same accumulator; and 4 launches of 16 frames"""
+    hs, _, acc, _ = full
+    cx = crt.Context(W, H)
+    hs.upload(cx)
+    cx.render(1, 40, 1)
+    cx.render(41, 24, 1)
+    assert np.array_equal(cx.accumulator(), acc)
+    cx.close()
+    cx = crt.Context(W, H, max_frames_per_launch=16)
+    hs.upload(cx)
+    cx.render(1, SPP, 1)
+    assert np.array_equal(cx.accumulator(), acc)
+    assert cx.timing()["render_launches"] == 4
+    cx.close()
+
+
+def test_config2_spot_tiles_against_oracle(orc, full):
+    """the oracle renders 6 of the 3600 tiles at full size (all 64 frames); those pixels must match bit for bit"""
+    _, _, acc, _ = full
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o.renderer_init(W, H)
+    tw = W // 16
+    tiles = [0, tw * 10 + 3, tw * 31 + 40, tw * 32 + 41, tw * 40 + 20, tw * 44 + 79]
+    for t in tiles:
+        o.clear()
+        o.set_tile_range(t, 1)
+        o.render(SPP, 1)
+        x0, y0 = (t % tw) * 16, (t // tw) * 16
+        want = o.accumulator()[y0:y0 + 16, x0:x0 + 16]
+        got = acc[y0:y0 + 16, x0:x0 + 16]
+        assert np.abs(got - want).max() / SPP <= 1e-4, t
+        assert np.array_equal(got, want), t
+
+
+def test_config3_tlas_full_size_spot_tiles(crt, orc):
+    """BASELINE config 3: TLASFileScene (wok + torii + teapot), 1280x720, 64 spp"""
+    hs = crt.HostScene(scene_path("tlas_scene.xml"), 1, ASSETS)
+    ctx = crt.Context(W, H)
+    hs.upload(ctx)
+    ctx.render(1, SPP, 1)
+    acc = ctx.accumulator()
+    assert np.isfinite(acc).all()
+    o, _ = orc.load_scene(scene_path("tlas_scene.xml"), 1, ASSETS)
+    o.renderer_init(W, H)
+    tw = W // 16
+    for t in [tw * 20 + 40, tw * 30 + 25, tw * 33 + 52]:
+        o.clear()
+        o.set_tile_range(t, 1)
+        o.render(SPP, 1)
+        x0, y0 = (t % tw) * 16, (t // tw) * 16
+        assert np.array_equal(acc[y0:y0 + 16, x0:x0 + 16], o.accumulator()[y0:y0 + 16, x0:x0 + 16]), t
+
+
+def test_config5_4k_tile_split_property(crt):
+    """BASELINE config 5 shape (3840x2160, tiles split across ranks) on one GPU: two interleaved half-images at 4 spp sum to the whole"""
+    hs = crt.HostScene(scene_path("tlas_scene.xml"), 1, ASSETS)
+    Wk, Hk = 3840, 2160
+    tiles = (Wk // 16) * (Hk // 16)
+    whole = crt.Context(Wk, Hk)
+    hs.upload(whole)
+    whole.render(1, 4, 1)
+    acc = whole.accumulator()
+    whole.close()
+    total = np.zeros_like(acc)
+    for r in range(2):
+        first, stride, count = crt.tile_partition(r, 2, tiles)
+        cx = crt.Context(Wk, Hk, tile_first=first, tile_stride=stride, tile_count=count)
+        hs.upload(cx)
+        cx.render(1, 4, 1)
+        total += cx.accumulator()
+        cx.close()
+    assert np.array_equal(total, acc)

@@ -1,0 +1,240 @@
+"""GPU tests against committed golden vectors (incl. outputs of the REAL reference), edge cases, and the C++ facade."""
+import ctypes as C
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, GOLDEN, scene_path
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(GOLDEN, "golden.json")))
+
+
+def crc(a):
+    return int(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff)
+
+
+def bits(a):
+    return np.asarray(a).view(np.uint32)
+
+
+def write_scene(tmp_path, mesh, name="s.xml", pos=(0.0, -1.0, 2.0), rot=(0.0, 180.0, 0.0), scale=(1.0, 1.0, 1.0), mats=None, extra_objects=()):
+    """scene equivalent to tests/golden/make_golden.py::simple_scene but through the XML loader (floor = pavement, sky = gradient)"""
+    mats = mats or [(0.0, 0.0, (0.0, 0.0, 0.0), "")]
+    objs = [(mesh, 0, pos, rot, scale)] + list(extra_objects)
+    o = "".join("<object><model_location>../assets/%s.obj</model_location><material_idx>%d</material_idx><position><x>%r</x><y>%r</y><z>%r</z></position>"
+                "<rotation><x>%r</x><y>%r</y><z>%r</z></rotation><scale><x>%r</x><y>%r</y><z>%r</z></scale></object>" % ((m, mi) + tuple(p) + tuple(r) + tuple(s))
+                for m, mi, p, r, s in objs)
+    ms = "".join("<material><reflectivity>%r</reflectivity><refractivity>%r</refractivity><absorption><x>%r</x><y>%r</y><z>%r</z></absorption><texture_location>%s</texture_location></material>"
+                 % ((a, b) + tuple(c) + (t,)) for a, b, c, t in mats)
+    p = tmp_path / name
+    p.write_text("<scene><scene_name>t</scene_name><light_position><x>0.0</x><y>3.0</y><z>1.0</z></light_position>"
+                 "<plane_texture_location>../assets/textures/Stylized_Pavement_basecolor.png</plane_texture_location>"
+                 "<skydome_location>../assets/sky_gradient.png</skydome_location><objects>%s</objects><materials>%s</materials></scene>" % (o, ms))
+    return str(p)
+
+
+@pytest.mark.parametrize("mesh", ["bunny", "teapot", "cube"])
+def test_gpu_traversal_vs_real_reference_golden(crt, tmp_path, mesh):
+    """rays traced by the reference's own BVH::Intersect (oracle/_ref, authoring container) vs the HIP find_nearest"""
+    z = np.load(os.path.join(GOLDEN, "ref_bvh_rays.npz"))
+    O, D = z[mesh + "_O"], z[mesh + "_D"]
+    hs = crt.HostScene(write_scene(tmp_path, mesh), 0, ASSETS)
+    b = hs.bvh(0)
+    g = G["ref_bvh"][mesh]
+    assert (b["nodesUsed"], b["maxDepth"], crc(b["nodes"]), crc(b["triIndices"])) == (g["nodesUsed"], g["maxDepth"], g["nodes"], g["triIndices"])
+    ctx = crt.Context(64, 64)
+    hs.upload(ctx)
+    h = ctx.find_nearest(O, D)
+    ro = z[mesh + "_objIdx"]
+    both = (h["objIdx"] >= 2) & (ro >= 2)
+    assert both.sum() > 200
+    for f in ("t", "u", "v"):
+        assert np.array_equal(bits(h[f][both]), bits(z[mesh + "_" + f][both])), f
+    assert np.array_equal(h["triIdx"][both], z[mesh + "_triIdx"][both])
+    miss = (h["objIdx"] == -1) & (ro == -1)
+    assert np.array_equal(h["traversed"][miss], z[mesh + "_traversed"][miss]) and np.array_equal(h["tested"][miss], z[mesh + "_tested"][miss])
+    assert not ((h["objIdx"] >= 2) & (ro < 2)).any()
+
+
+@pytest.mark.parametrize("name", sorted(G["orc_render"].keys()))
+def test_gpu_render_vs_golden_accumulator(crt, name):
+    g = G["orc_render"][name]
+    hs = crt.HostScene(scene_path(g["xml"]), g["kind"], ASSETS)
+    ctx = crt.Context(g["W"], g["H"], collect_stats=True)
+    hs.upload(ctx)
+    ctx.render(1, g["frames"], 1)
+    acc = ctx.accumulator()
+    want = np.load(os.path.join(GOLDEN, "orc_render_%s.npy" % name))
+    assert np.abs(acc - want).max() / g["frames"] <= 1e-4
+    assert np.array_equal(acc, want)
+    assert ctx.counters() == g["counters"]
+    px, energy = ctx.resolve_screen(1.0 / (g["frames"] + 1))
+    assert crc(px) == g["screen"] and float(np.float32(energy)) == g["energy"]
+
+
+def test_passes_and_frame_batches_are_order_exact(crt, orc):
+    """passes = 3 (three samples per pixel per Tick) and launches of 5 frames (lanes 5..63 idle) against the oracle"""
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(64, 48, max_frames_per_launch=5)
+    hs.upload(ctx)
+    ctx.render(1, 7, 3)                      # spp 1,4,...,19
+    acc = ctx.accumulator()
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o.renderer_init(64, 48)
+    o.set_params(5, 3)
+    o.render(7, 2)
+    assert np.array_equal(acc, o.accumulator())
+    assert ctx.timing()["render_launches"] == 2
+
+
+def test_resolution_not_multiple_of_16_leaves_trailing_pixels_untouched(crt, orc):
+    """SCRHEIGHT/16 truncates (renderer.cpp:151): rows >= 16*(H//16) and columns >= 16*(W//16) are never rendered"""
+    W, H = 100, 72
+    hs = crt.HostScene(scene_path("cube_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(W, H)
+    hs.upload(ctx)
+    ctx.render(1, 2, 1)
+    acc = ctx.accumulator()
+    assert not acc[64:, :, :].any() and not acc[:, 96:, :].any() and acc[:64, :96, :3].any()
+    o, _ = orc.load_scene(scene_path("cube_scene.xml"), 0, ASSETS)
+    o.renderer_init(W, H)
+    o.render(2, 2)
+    assert np.array_equal(acc, o.accumulator())
+
+
+@pytest.mark.parametrize("depth", [0, 1, 3])
+def test_depth_limit(crt, orc, depth):
+    hs = crt.HostScene(scene_path("tlas_scene.xml"), 1, ASSETS)
+    ctx = crt.Context(64, 48, depth_limit=depth)
+    hs.upload(ctx)
+    ctx.render(1, 2, 1)
+    o, _ = orc.load_scene(scene_path("tlas_scene.xml"), 1, ASSETS)
+    o.renderer_init(64, 48)
+    o.set_params(depth, 1)
+    o.render(2, 2)
+    assert np.array_equal(ctx.accumulator(), o.accumulator())
+    assert ctx.counters()["rays"] == o.counters()["rays"]
+
+
+def test_camera_state_and_clear(crt, orc):
+    hs = crt.HostScene(scene_path("tlas_scene.xml"), 1, ASSETS)
+    ctx = crt.Context(80, 48)
+    hs.upload(ctx)
+    ctx.render(1, 1, 1)
+    ctx.clear()
+    ctx.set_camera_state((2.0, 0.5, -1.5), (0.0, -0.5, 3.0))
+    ctx.render(1, 2, 1)
+    o, _ = orc.load_scene(scene_path("tlas_scene.xml"), 1, ASSETS)
+    o.renderer_init(80, 48)
+    o.set_camera_state((2.0, 0.5, -1.5), (0.0, -0.5, 3.0))
+    o.render(2, 2)
+    assert np.array_equal(ctx.accumulator(), o.accumulator())
+
+
+def test_materials_mirror_dielectric_absorption_texture(crt, orc, tmp_path):
+    """every Sample branch: mirror, dielectric with absorption (inside rays, expf), textured diffuse, and a camera inside the glass teapot"""
+    xml = write_scene(tmp_path, "teapot", pos=(0.0, -1.0, 2.5), rot=(0.0, 30.0, 0.0), scale=(0.5, 0.5, 0.5),
+                      mats=[(0.1, 0.85, (0.8, 0.2, 0.1), ""), (1.0, 0.0, (0.0, 0.0, 0.0), ""), (0.0, 0.0, (0.0, 0.0, 0.0), "../assets/textures/Stylized_Wood_basecolor.tga")],
+                      extra_objects=[("cube", 1, (-1.6, -0.5, 3.0), (0.0, 20.0, 0.0), (0.5, 0.5, 0.5)), ("log_fence", 2, (1.8, -1.0, 3.0), (0.0, 0.0, 0.0), (0.6, 0.6, 0.6))])
+    for kind in (0, 1):
+        hs = crt.HostScene(xml, kind, ASSETS)
+        ctx = crt.Context(96, 64, collect_stats=True)
+        hs.upload(ctx)
+        ctx.render(1, 3, 1)
+        o, _ = orc.load_scene(xml, kind, ASSETS)
+        o.renderer_init(96, 64)
+        o.render(3, 2)
+        assert np.array_equal(ctx.accumulator(), o.accumulator()), kind
+        assert ctx.counters() == o.counters()
+
+
+def test_tiny_mesh_root_is_leaf_and_single_blas(crt, orc, tmp_path):
+    """2 triangles: BVH root stays a leaf (triCount <= 2), TLAS with one BLAS: root node is a TLAS leaf"""
+    obj = tmp_path / "quad.obj"
+    obj.write_text("v -1 0 0\nv 1 0 0\nv 1 1.5 0\nv -1 1.5 0\nvn 0 0 -1\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1/1 2/2/1 3/3/1 4/4/1\n")
+    xml = tmp_path / "quad.xml"
+    xml.write_text(open(scene_path("bunny_scene.xml")).read().replace("../assets/bunny.obj", str(obj)).replace("<y>-1.0</y><z>2.0</z>", "<y>-1.0</y><z>3.0</z>"))
+    for kind in (0, 1):
+        hs = crt.HostScene(str(xml), kind, ASSETS)
+        assert hs.bvh(0)["nodesUsed"] == 1
+        ctx = crt.Context(64, 48, collect_stats=True)
+        hs.upload(ctx)
+        ctx.render(1, 2, 1)
+        o, _ = orc.load_scene(str(xml), kind, ASSETS)
+        o.renderer_init(64, 48)
+        o.render(2, 1)
+        assert np.array_equal(ctx.accumulator(), o.accumulator()), kind
+        assert ctx.counters() == o.counters()
+        assert ctx.counters()["mesh_hits"] > 0
+
+
+def test_axis_aligned_rays_nan_exact_slab_path(crt, orc):
+    """direction components that are exactly 0 make rD infinite and 0*inf = NaN in the slab test: the kernel must fall back
+    to the reference's std::min/std::max operand order (box_exact) and still agree bit for bit"""
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(64, 64)
+    hs.upload(ctx)
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    b = hs.bvh(0)
+    n = b["nodes"][: b["nodesUsed"]]
+    pts = np.concatenate([n["aabbMin"], n["aabbMax"]])[:4000].astype(np.float32)      # origins exactly on box planes
+    O = np.concatenate([pts - np.array([0, 0, 5], np.float32), pts - np.array([5, 0, 0], np.float32), pts + np.array([0, 5, 0], np.float32)])
+    D = np.concatenate([np.tile(np.array([0, 0, 1], np.float32), (len(pts), 1)), np.tile(np.array([1, 0, 0], np.float32), (len(pts), 1)),
+                        np.tile(np.array([0, -1, 0], np.float32), (len(pts), 1))])
+    g, c = ctx.find_nearest(O, D), o.find_nearest(O, D)
+    for f in ("objIdx", "triIdx", "traversed", "tested"):
+        assert np.array_equal(g[f], c[f]), f
+    for f in ("t", "u", "v"):
+        assert np.array_equal(bits(g[f]), bits(c[f])), f
+    assert (g["objIdx"] >= 2).sum() > 100
+
+
+def test_error_codes(crt):
+    hs = crt.HostScene(scene_path("cube_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(64, 48)
+    with pytest.raises(crt.CrtError) as e:
+        ctx.render(1, 1, 1)                 # before upload
+    assert e.value.code == -5
+    hs.upload(ctx)
+    with pytest.raises(crt.CrtError) as e:
+        ctx.render(1, 1, 9)                 # passes outside 1..4
+    assert e.value.code == -1
+    ctx.render(1, 0, 1)                     # zero frames: no-op
+    assert not ctx.accumulator().any()
+    assert len(ctx.find_nearest(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))) == 0
+    with pytest.raises(crt.CrtError):
+        crt.Context(8, 8)                   # smaller than one tile
+    with pytest.raises(crt.CrtError):
+        crt.Context(64, 64, tile_first=10, tile_stride=1, tile_count=100)
+    with pytest.raises(crt.CrtError):
+        crt.Context(64, 64, depth_limit=9)
+
+
+def test_renderer_facade_tick_semantics(crt, orc):
+    """Renderer::Init / Tick / ClearAccumulator through the C++ facade: spp, energy, screen, accumulator as the reference leaves them"""
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    r = crt.HostRenderer(hs, 96, 64)
+    r.init()
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o.renderer_init(96, 64)
+    assert r.spp == 1
+    for k in range(3):
+        r.tick(16.0)
+        o.render(1, 2)
+        assert r.spp == o.spp() == k + 2
+        assert np.array_equal(r.accumulator(), o.accumulator())
+        assert np.array_equal(r.screen(), o.screen())
+        assert r.energy == o.energy()
+    r.render(4)                              # four Ticks in one submission
+    o.render(4, 2)
+    assert r.spp == 8 and np.array_equal(r.accumulator(), o.accumulator()) and np.array_equal(r.screen(), o.screen())
+    r.clear()
+    assert not r.accumulator().any() and r.spp == 8        # ClearAccumulator does not touch spp (renderer.cpp:15-18)
+    r.set_camera((0.5, 0.2, -2.5), (0.0, -0.4, 2.0))
+    r.tick(16.0)
+    o.clear(); o.set_spp(8); o.set_camera_state((0.5, 0.2, -2.5), (0.0, -0.4, 2.0)); o.render(1, 2)
+    assert np.array_equal(r.accumulator(), o.accumulator())

@@ -1,0 +1,141 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every declared symbol, the C++ host front
+(own OBJ / XML / image loaders + CPU SAH-BVH / TLAS build) reproduces the oracle's structures bit for bit, and errors come
+back as codes.  No compute call is made (there is no GPU here and the library has no CPU path)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, REPO, scene_path
+
+SCENES = [("bunny_scene.xml", 0), ("cube_scene.xml", 0), ("tlas_scene.xml", 1), ("tlas_scene.xml", 0)]
+
+
+def test_library_exports_every_declared_symbol(crt):
+    lib = crt.lib()
+    declared = []
+    for hdr in ("crt_abi.h", "crt_host.h"):
+        text = open(os.path.join(REPO, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared += re.findall(r"\b(crt_[a-z_0-9]+)\s*\(", text)
+    declared = sorted(set(declared))
+    assert len(declared) >= 40
+    for sym in declared:
+        assert hasattr(lib, sym), "include/*.h declares %s but libcrt_amd.so does not export it" % sym
+    assert set(crt.ABI_SYMBOLS + crt.HOST_SYMBOLS) == set(declared)
+    assert lib.crt_abi_version() == 1
+
+
+def test_record_layouts(crt):
+    assert crt.TRI_DTYPE.itemsize == 112 and crt.NODE_DTYPE.itemsize == 32 and crt.TLAS_DTYPE.itemsize == 32
+    assert C.sizeof(crt.Config) == 36 and C.sizeof(crt.CountersS) == 64
+
+
+@pytest.mark.parametrize("xml,kind", SCENES)
+def test_host_build_matches_oracle(crt, orc, xml, kind):
+    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    o, _ = orc.load_scene(scene_path(xml), kind, ASSETS)
+    assert hs.bvh_count() == o.bvh_count()
+    for i in range(hs.bvh_count()):
+        a, b = hs.bvh(i), o.bvh(i)
+        assert (a["nodesUsed"], a["maxDepth"]) == (b["nodesUsed"], b["maxDepth"])
+        for k in ("nodes", "triIndices", "tris"):
+            assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (i, k)
+        if kind == 1:
+            for x, y in zip(hs.blas_transform(i), o.blas_transform(i)):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    if kind == 1:
+        (na, ua), (nb, ub) = hs.tlas(), o.tlas()
+        assert ua == ub and np.array_equal(na.view(np.uint8), nb.view(np.uint8))
+
+
+def test_loaders_match_independent_readers(crt, orc):
+    for m in ("cube", "bunny", "teapot", "wok", "japanese_torii_gate", "watch-tower", "log_fence"):
+        p = os.path.join(ASSETS, m + ".obj")
+        for a, b in zip(crt.load_obj(p), orc.read_obj(p)):
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), m
+    for f in ("textures/Stylized_Pavement_basecolor.png", "textures/Stylized_Wood_basecolor.tga", "textures/Defuse_wok.png", "sky_gradient.png"):
+        p = os.path.join(ASSETS, f)
+        assert np.array_equal(crt.load_image(p), orc.pack_rgb(orc.read_image(p))), f
+
+
+def test_obj_edge_cases(crt, orc, tmp_path):
+    """ragged input: relative indices, missing vt/vn, quads on either diagonal, a pentagon, blank lines, CRLF, exponents."""
+    text = "\r\n".join([
+        "# comment", "", "v 0 0 0", "v 1 0 0", "v 1 1 0", "v 0 1 0", "v 0.5 1.5e0 0", "v 2 0 1", "v 2 1.0 -.5", "v +3 0 0",
+        "vn 0 0 1", "vt 0.25 0.75", "o thing", "s off",
+        "f 1 2 3", "f 1//1 2//1 3//1", "f 1/1 2/1 3/1", "f 1/1/1 2/1/1 3/1/1",
+        "f -8 -7 -6", "f 1 2 3 4", "f 2 6 7 3", "f 1 2 3 5 4", "f 1 2", ""])
+    p = tmp_path / "edge.obj"
+    p.write_bytes(text.encode())
+    a, b = crt.load_obj(str(p)), orc.read_obj(str(p))
+    assert a[0].shape[0] == 3 * (5 + 2 + 2 + 3)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+def test_loader_errors_are_codes_not_crashes(crt, tmp_path):
+    with pytest.raises(crt.CrtError) as e:
+        crt.HostScene(str(tmp_path / "nope.xml"), 0, ASSETS)
+    assert e.value.code == -6 and "nope.xml" in str(e.value)
+    bad = tmp_path / "bad.xml"
+    bad.write_text("<scene><scene_name>x</scene_name></scene>")
+    with pytest.raises(crt.CrtError) as e:
+        crt.HostScene(str(bad), 0, ASSETS)
+    assert e.value.code == -6 and "light_position" in str(e.value)
+    xml = open(scene_path("bunny_scene.xml")).read().replace("../assets/bunny.obj", "../assets/missing_model.obj")
+    m = tmp_path / "missing_model.xml"
+    m.write_text(xml)
+    with pytest.raises(crt.CrtError) as e:
+        crt.HostScene(str(m), 0, ASSETS)
+    assert "missing_model.obj" in str(e.value)
+    with pytest.raises(crt.CrtError):
+        crt.load_obj(str(tmp_path / "absent.obj"))
+    zero = tmp_path / "zero.obj"
+    zero.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 1 2\n")          # index 0 is invalid in OBJ
+    with pytest.raises(crt.CrtError):
+        crt.load_obj(str(zero))
+    with pytest.raises(crt.CrtError):
+        crt.HostScene(scene_path("bunny_scene.xml"), 7, ASSETS)       # unknown scene kind
+
+
+def test_material_index_out_of_range_is_rejected(crt, tmp_path):
+    xml = open(scene_path("bunny_scene.xml")).read().replace("<material_idx>0</material_idx>", "<material_idx>3</material_idx>")
+    p = tmp_path / "badmat.xml"
+    p.write_text(xml)
+    with pytest.raises(crt.CrtError) as e:
+        crt.HostScene(str(p), 0, ASSETS)
+    assert "material_idx" in str(e.value)
+
+
+def test_camera_state_matches_oracle(crt, orc):
+    o, _ = orc.load_scene(scene_path("cube_scene.xml"), 0, ASSETS)
+    o.renderer_init(1280, 720)
+    o.set_camera_state((1.5, 0.7, -3.0), (0.2, -0.1, 2.0))
+    want = o.camera()
+    got = [(C.c_float * 3)() for _ in range(4)]
+    lib = crt.lib()
+    assert lib.crt_host_camera_state(1280, 720, (C.c_float * 3)(1.5, 0.7, -3.0), (C.c_float * 3)(0.2, -0.1, 2.0), *got) == 0
+    for g, w in zip(got, want):
+        assert np.array_equal(np.array(list(g), np.float32).view(np.uint32), w.view(np.uint32))
+
+
+def test_no_device_means_error_not_fallback(crt):
+    """The product must fail loudly without a HIP device — never route through the oracle or any CPU path."""
+    if crt.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(crt.CrtError) as e:
+        crt.Context(64, 64)
+    assert e.value.code == -3
+
+
+def test_product_does_not_reference_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/"""
+    pkg = os.path.join(REPO, "cpu-ray-tracer_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "crt_oracle" not in text and "import orc" not in text and "oracle/" not in text.replace("oracle/_ref", ""), os.path.join(root, f)

@@ -1,0 +1,212 @@
+"""CPU tests that pin the oracle:
+  * against the REAL reference compiled in place (oracle/_ref: infra/bvh.cpp, tinyobj, stb_image) — authoring container only;
+  * against the committed golden vectors those runs produced (tests/golden/ref_*) — everywhere, including the GPU box;
+  * regression vectors for the parts with no executable reference (tests/golden/orc_*, "parity unpinned")."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, GOLDEN, scene_path
+
+G = json.load(open(os.path.join(GOLDEN, "golden.json")))
+MESHES = sorted(G["ref_bvh"].keys())
+
+
+def crc(a):
+    return int(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff)
+
+
+def simple_scene(orc, mesh, kind=0):
+    o = orc.Oracle(kind)
+    o.set_light_position((0, 3, 1))
+    o.set_floor_texture(np.full((512, 512), 0x808080, np.uint32))
+    o.set_skydome(np.full((4, 8), 0x6080c0, np.uint32))
+    o.add_material()
+    o.add_object(orc.read_obj(os.path.join(ASSETS, mesh + ".obj")), (0, -1, 2), (0, 180, 0), (1, 1, 1), 0)
+    o.build()
+    return o
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# golden vectors produced by the real reference
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mesh", MESHES)
+def test_obj_reader_matches_tinyobj_golden(orc, mesh):
+    pos, nrm, uv = orc.read_obj(os.path.join(ASSETS, mesh + ".obj"))
+    g = G["ref_obj"][mesh]
+    assert pos.shape[0] == g["corners"]
+    assert (crc(pos), crc(nrm), crc(uv)) == (g["pos"], g["nrm"], g["uv"])
+
+
+@pytest.mark.parametrize("img", sorted(G["ref_img"].keys()))
+def test_image_reader_matches_stb_golden(orc, img):
+    a = orc.read_image(os.path.join(ASSETS, img))
+    assert list(a.shape) == G["ref_img"][img]["shape"]
+    assert crc(orc.pack_rgb(a)) == G["ref_img"][img]["packed"]
+
+
+@pytest.mark.parametrize("mesh", MESHES)
+def test_oracle_bvh_build_matches_reference_golden(orc, mesh):
+    b = simple_scene(orc, mesh).bvh(0)
+    g = G["ref_bvh"][mesh]
+    assert crc(b["tris"]) == g["tris_crc"], "triangle soup differs: the build comparison would be meaningless"
+    assert (b["nodesUsed"], b["maxDepth"]) == (g["nodesUsed"], g["maxDepth"])
+    assert crc(b["nodes"]) == g["nodes"] and crc(b["triIndices"]) == g["triIndices"]
+
+
+@pytest.mark.parametrize("mesh", ["bunny", "teapot", "cube"])
+def test_oracle_traversal_matches_reference_golden(orc, mesh):
+    """Rays against BVH::Intersect of the reference.  The oracle's FindNearest tests the light quad and the floor first;
+    rays are compared where the mesh is (or is not) the nearest thing in both."""
+    z = np.load(os.path.join(GOLDEN, "ref_bvh_rays.npz"))
+    O, D = z[mesh + "_O"], z[mesh + "_D"]
+    o = simple_scene(orc, mesh)
+    h = o.find_nearest(O, D)
+    rt, ro = z[mesh + "_t"], z[mesh + "_objIdx"]
+    both = (h["objIdx"] >= 2) & (ro >= 2)
+    assert both.sum() > 200
+    for f in ("t", "u", "v"):
+        assert np.array_equal(h[f][both].view(np.uint32), z[mesh + "_" + f][both].view(np.uint32)), f
+    assert np.array_equal(h["triIdx"][both], z[mesh + "_triIdx"][both])
+    other = (ro >= 2) & ~(h["objIdx"] >= 2)          # reference hit the mesh, oracle reports floor / light: must be nearer
+    assert np.all(h["t"][other] < rt[other])
+    assert not ((h["objIdx"] >= 2) & (ro < 2)).any()
+    miss = (h["objIdx"] == -1) & (ro == -1)             # nothing shortened t before the traversal: loop-trip counters must agree
+    assert np.array_equal(h["traversed"][miss], z[mesh + "_traversed"][miss])
+    assert np.array_equal(h["tested"][miss], z[mesh + "_tested"][miss])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# live comparison with the real reference (authoring container)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mesh", ["bunny", "wok", "teapot"])
+def test_oracle_vs_reference_live(orc, ref, mesh):
+    o = simple_scene(orc, mesh)
+    b = o.bvh(0)
+    h, rb = ref.bvh_build(b["tris"])
+    try:
+        assert rb["nodesUsed"] == b["nodesUsed"] and rb["maxDepth"] == b["maxDepth"]
+        assert np.array_equal(rb["nodes"].view(np.uint8), b["nodes"].view(np.uint8))
+        assert np.array_equal(rb["triIndices"], b["triIndices"])
+        rng = np.random.default_rng(99)
+        n = 20000
+        O = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+        O[:, 1] = np.abs(O[:, 1]) + 0.2
+        T = rng.uniform(-1, 1, (n, 3)).astype(np.float32) + np.array([0, -0.3, 2], np.float32)
+        D = T - O
+        D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+        rh = ref.bvh_intersect(h, O, D)
+        oh = o.find_nearest(O, D)
+        both = (oh["objIdx"] >= 2) & (rh["objIdx"] >= 2)
+        assert both.sum() > 1000
+        for f in ("t", "u", "v"):
+            assert np.array_equal(oh[f][both].view(np.uint32), rh[f][both].view(np.uint32))
+        assert np.array_equal(oh["triIdx"][both], rh["triIdx"][both])
+    finally:
+        ref.bvh_free(h)
+
+
+def test_python_readers_vs_reference_live(orc, ref):
+    for m in MESHES:
+        mine, theirs = orc.read_obj(os.path.join(ASSETS, m + ".obj")), ref.obj_load(os.path.join(ASSETS, m + ".obj"))
+        for a, b in zip(mine, theirs):
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), m
+    for f in G["ref_img"]:
+        assert np.array_equal(orc.read_image(os.path.join(ASSETS, f)), ref.image_load(os.path.join(ASSETS, f))), f
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# oracle regression vectors (integrator etc.: no executable reference exists — "parity unpinned")
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(G["orc_render"].keys()))
+def test_oracle_render_regression(orc, name):
+    g = G["orc_render"][name]
+    o, _ = orc.load_scene(scene_path(g["xml"]), g["kind"], ASSETS)
+    o.renderer_init(g["W"], g["H"])
+    o.render(g["frames"], 2)
+    acc = o.accumulator()
+    assert np.array_equal(acc, np.load(os.path.join(GOLDEN, "orc_render_%s.npy" % name)))
+    assert crc(acc) == g["acc"] and crc(o.screen()) == g["screen"]
+    assert o.counters() == g["counters"]
+    assert float(np.float32(o.energy())) == g["energy"]
+    seeds = [o.tile_seed(g["frames"], t) for t in range((g["W"] // 16) * (g["H"] // 16))]
+    assert crc(np.array(seeds, np.uint32)) == g["last_frame_tile_seeds"]
+
+
+def test_oracle_thread_count_invariance(orc):
+    """renderer.cpp:120 seeds one stream per (tile, frame): the image cannot depend on the tile schedule."""
+    res = []
+    for threads in (1, 5):
+        o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+        o.renderer_init(80, 64)
+        o.render(3, threads)
+        res.append(o.accumulator())
+    assert np.array_equal(res[0], res[1])
+
+
+def test_whitted_config1_regression(orc):
+    """BASELINE config 1: cube.obj FileScene, Whitted-style, 640x360, CPU reference path (plumbing, no GPU)."""
+    o, _ = orc.load_scene(scene_path("cube_scene.xml"), 0, ASSETS)
+    o.renderer_init(640, 360)
+    o.whitted(4)
+    g = G["orc_whitted_cube_640x360"]
+    acc = o.accumulator()
+    assert np.isfinite(acc).all() and acc[..., :3].max() > 0.5
+    assert crc(acc) == g["acc"] and crc(o.screen()) == g["screen"] and o.counters() == g["counters"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# small known-answer checks of the restated primitives
+# ---------------------------------------------------------------------------------------------------------------
+def test_rng_known_answers(orc):
+    L = orc.lib()
+
+    def wang(s):
+        s = ((s ^ 61) ^ (s >> 16)) & 0xffffffff
+        s = (s * 9) & 0xffffffff
+        s ^= s >> 4
+        s = (s * 0x27d4eb2d) & 0xffffffff
+        s ^= s >> 15
+        return s
+    for base in (0, 1, 1799, 123456789, 0xffffffff):
+        assert L.orc_init_seed(base) == wang(((base + 1) * 17) & 0xffffffff)
+    import ctypes as C
+    s = C.c_uint32(0x12345678)
+    x = 0x12345678
+    for _ in range(100):
+        x ^= (x << 13) & 0xffffffff
+        x ^= x >> 17
+        x ^= (x << 5) & 0xffffffff
+        assert L.orc_random_uint(C.byref(s)) == x and s.value == x
+
+
+def test_deterministic_math_accuracy(orc):
+    """crt_expf / crt_atan2f / crt_acosf are the path's only transcendental functions (absorption, skydome lookup);
+    they must stay within a few ulp of the correctly rounded result."""
+    L = orc.lib()
+    rng = np.random.default_rng(5)
+
+    def ulps(got, want):
+        got = np.asarray(got, np.float32)
+        want32 = want.astype(np.float32)
+        sp = np.spacing(np.abs(want32)).astype(np.float64)
+        return np.abs(got.astype(np.float64) - want) / np.maximum(sp, 1e-45)
+    x = np.concatenate([rng.uniform(-40, 0, 4000), rng.uniform(-90, 80, 2000), [0.0, -0.0, -1e-8]]).astype(np.float32)
+    e = np.array([L.orc_expf(float(v)) for v in x], np.float32)
+    assert ulps(e, np.exp(x.astype(np.float64))).max() <= 2.0
+    assert L.orc_expf(0.0) == 1.0 and L.orc_expf(-0.0) == 1.0
+    y = rng.uniform(-1, 1, 6000).astype(np.float32)
+    xx = rng.uniform(-1, 1, 6000).astype(np.float32)
+    a = np.array([L.orc_atan2f(float(p), float(q)) for p, q in zip(y, xx)], np.float32)
+    assert np.abs(a.astype(np.float64) - np.arctan2(y.astype(np.float64), xx.astype(np.float64))).max() <= 6e-7
+    c = np.concatenate([rng.uniform(-1, 1, 6000), [1.0, -1.0, 0.0, 0.5, -0.5]]).astype(np.float32)
+    ac = np.array([L.orc_acosf(float(v)) for v in c], np.float32)
+    assert np.abs(ac.astype(np.float64) - np.arccos(c.astype(np.float64))).max() <= 6e-7
+    assert L.orc_atan2f(0.0, -1.0) == np.float32(np.pi) and L.orc_atan2f(0.0, 1.0) == 0.0
+
+
+def test_reference_struct_sizes(orc):
+    assert orc.TRI_DTYPE.itemsize == 112 and orc.NODE_DTYPE.itemsize == 32 and orc.TLAS_DTYPE.itemsize == 32
