@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -19,7 +20,7 @@ extern "C" hipError_t crt_launch_resolve(const void*, uint32_t*, float*, uint32_
 
 static_assert(sizeof(crt_bvh_node) == 32 && sizeof(crt_tri) == 112 && sizeof(crt_tlas_node) == 32, "reference layouts");
 static_assert(sizeof(crt::NodePair) == 64 && sizeof(crt::LeafTri) == 48 && sizeof(crt::ShadeTri) == 64 && sizeof(crt::TlasNode) == 32 &&
-              sizeof(crt::Instance) == 128 && sizeof(crt::Material) == 32, "device layouts");
+              sizeof(crt::Instance) == 128 && sizeof(crt::Material) == 32 && offsetof(crt::Instance, T) == 64, "device layouts");
 static_assert(sizeof(crt_counters) == sizeof(crt::Counters), "counter layout");
 
 namespace {
@@ -100,22 +101,6 @@ int bvh_height(crt_ctx* c, const crt_bvh& b, uint32_t* heightOut)
         st.push_back({nd.leftFirst, d + 1}); st.push_back({nd.leftFirst + 1, d + 1});
     }
     *heightOut = h;
-    return 0;
-}
-
-// packed GLOBAL reference of node n of BVH b whose pairs / leaf slots start at pairBase / leafBase (layout.h)
-int node_ref(crt_ctx* c, const crt_bvh& b, uint32_t n, uint32_t pairBase, uint32_t leafBase, uint32_t* ref)
-{
-    const crt_bvh_node& nd = b.nodes[n];
-    if (nd.triCount > 0) {
-        if (nd.triCount > crt::kMaxLeafTris)
-            return c->fail(CRT_ERR_UNSUPPORTED, "leaf with %u triangles: this build packs at most %u per leaf", nd.triCount, crt::kMaxLeafTris);
-        if ((uint64_t)nd.leftFirst + nd.triCount > b.triCount) return c->fail(CRT_ERR_INVALID, "leaf range out of bounds (node %u)", n);
-        *ref = (nd.triCount << 24) | (leafBase + nd.leftFirst);
-    } else {
-        if ((nd.leftFirst & 1u) == 0) return c->fail(CRT_ERR_INVALID, "interior node %u: children must be allocated pairwise starting at an odd index", n);
-        *ref = crt::kRefInterior | (pairBase + ((nd.leftFirst - 1u) >> 1));
-    }
     return 0;
 }
 
@@ -228,73 +213,112 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         if (!sd->textures[i].pixels || sd->textures[i].width <= 0 || sd->textures[i].height <= 0) return c->fail(CRT_ERR_INVALID, "texture %u is empty", i);
     for (uint32_t i = 0; i < sd->materialCount; i++)
         if (sd->materials[i].texture >= (int)sd->textureCount) return c->fail(CRT_ERR_INVALID, "material %u: texture index out of range", i);
+    if (sd->kind == CRT_SCENE_FILE) {
+        if (!sd->objMatIdx || sd->objCount == 0) return c->fail(CRT_ERR_INVALID, "CRT_SCENE_FILE needs objMatIdx");
+        for (uint32_t i = 0; i < sd->objCount; i++)
+            if (sd->objMatIdx[i] < 0 || sd->objMatIdx[i] >= (int)sd->materialCount) return c->fail(CRT_ERR_INVALID, "objMatIdx entry out of range");
+    }
 
-    c->freeScene();
-    std::vector<crt::NodePair> pairs; std::vector<crt::LeafTri> leaf; std::vector<crt::ShadeTri> shade; std::vector<crt::Instance> inst;
-    uint32_t maxHeight = 0, rootRef0 = 0;
+    // ---- sizes of the sections of the geometry buffer: pairs | leaf tris (+1 pad record) | TLAS nodes | instances | shade records ----
+    uint64_t nPairs = 0, nTris = 0;
+    uint32_t maxHeight = 0;
     for (uint32_t bi = 0; bi < sd->bvhCount; bi++) {
         const crt_bvh& b = sd->bvhs[bi];
         if (!b.nodes || !b.triangles || !b.triangleIndices || b.nodesUsed == 0 || b.triCount == 0) return c->fail(CRT_ERR_INVALID, "BVH %u is empty", bi);
         if ((b.nodesUsed & 1u) == 0) return c->fail(CRT_ERR_INVALID, "BVH %u: nodesUsed must be odd (root + child pairs)", bi);
         if (sd->kind == CRT_SCENE_TLAS && (b.matIdx < 0 || b.matIdx >= (int)sd->materialCount)) return c->fail(CRT_ERR_INVALID, "BLAS %u: matIdx out of range", bi);
+        if (sd->kind == CRT_SCENE_TLAS && b.objIdx != (int)bi + 2)
+            return c->fail(CRT_ERR_INVALID, "BLAS %u: objIdx must be %u (TLASFileScene numbers objects from 2, tlas_file_scene.cpp:13,51-53)", bi, bi + 2);
         uint32_t h = 0; int r = bvh_height(c, b, &h); if (r) return r;
         if (h > maxHeight) maxHeight = h;
-        const uint32_t pairBase = (uint32_t)pairs.size(), leafBase = (uint32_t)leaf.size(), shadeBase = (uint32_t)shade.size();
-        if ((uint64_t)leafBase + b.triCount > crt::kMaxLeafSlots) return c->fail(CRT_ERR_UNSUPPORTED, "more than 2^24 triangles in the scene");
-        if ((uint64_t)pairBase + b.nodesUsed / 2 > crt::kMaxPairs) return c->fail(CRT_ERR_UNSUPPORTED, "more than 2^30 node pairs in the scene");
-        // node pairs
+        nPairs += b.nodesUsed / 2; nTris += b.triCount;
+    }
+    const uint64_t pairBytes = nPairs ? nPairs * 64 : 64;                   // offset 0 must never be a leaf record (ref 0 = "done")
+    const uint64_t leafOffB = pairBytes, leafBytes = (nTris + 1) * 48;       // +1: record fetches read 64 B from a 48-B LeafTri
+    const uint64_t tlasOffB = (leafOffB + leafBytes + 63) & ~63ull;
+    const uint64_t tlasBytes = (sd->kind == CRT_SCENE_TLAS) ? (uint64_t)sd->tlasNodeCount * 32 : 0;
+    const uint64_t instOffB = (tlasOffB + tlasBytes + 127) & ~127ull;
+    const uint64_t instBytes = (sd->kind == CRT_SCENE_TLAS) ? (uint64_t)sd->bvhCount * 128 : 0;
+    const uint64_t shadeOffB = (instOffB + instBytes + 63) & ~63ull;
+    const uint64_t total = shadeOffB + nTris * 64;
+    if (total >= crt::kMaxGeomBytes) return c->fail(CRT_ERR_UNSUPPORTED, "scene geometry needs %llu bytes; this build addresses 4 GiB", (unsigned long long)total);
+    if (sd->kind == CRT_SCENE_TLAS && sd->tlasNodeCount > 0x7fffu) return c->fail(CRT_ERR_UNSUPPORTED, "TLAS node index exceeds 15 bits");
+
+    std::vector<char> geom((size_t)total, 0);
+    crt::NodePair* pairs = reinterpret_cast<crt::NodePair*>(geom.data());
+    crt::LeafTri* leaf = reinterpret_cast<crt::LeafTri*>(geom.data() + leafOffB);
+    crt::TlasNode* tlas = reinterpret_cast<crt::TlasNode*>(geom.data() + tlasOffB);
+    crt::Instance* inst = reinterpret_cast<crt::Instance*>(geom.data() + instOffB);
+    crt::ShadeTri* shade = reinterpret_cast<crt::ShadeTri*>(geom.data() + shadeOffB);
+
+    uint64_t pairBase = 0, triBase = 0; uint32_t rootRef0 = 0;
+    for (uint32_t bi = 0; bi < sd->bvhCount; bi++) {
+        const crt_bvh& b = sd->bvhs[bi];
+        // packed reference of node n (layout.h): interior -> offset of its child pair, leaf -> offset of its first LeafTri, both in 16-byte units
+        auto ref_of = [&](uint32_t n, uint32_t* ref) -> int {
+            const crt_bvh_node& nd = b.nodes[n];
+            if (nd.triCount > 0) {
+                if ((uint64_t)nd.leftFirst + nd.triCount > b.triCount) return c->fail(CRT_ERR_INVALID, "leaf range out of bounds (BVH %u node %u)", bi, n);
+                *ref = (uint32_t)((leafOffB + (triBase + nd.leftFirst) * 48) >> 4);
+            } else {
+                if ((nd.leftFirst & 1u) == 0) return c->fail(CRT_ERR_INVALID, "interior node %u: children must be allocated pairwise starting at an odd index", n);
+                *ref = crt::kRefInterior | (uint32_t)(((pairBase + ((nd.leftFirst - 1u) >> 1)) * 64) >> 4);
+            }
+            return 0;
+        };
+        int r;
         for (uint32_t n = 1; n + 1 < b.nodesUsed; n += 2) {
-            crt::NodePair p; memset(&p, 0, sizeof(p));
+            crt::NodePair& p = pairs[pairBase + ((n - 1) >> 1)];
             for (int k = 0; k < 2; k++) {
                 const crt_bvh_node& nd = b.nodes[n + k];
                 memcpy(p.c[k].lo, nd.aabbMin, 12); memcpy(p.c[k].hi, nd.aabbMax, 12);
-                r = node_ref(c, b, n + k, pairBase, leafBase, &p.c[k].ref); if (r) return r;
+                if ((r = ref_of(n + k, &p.c[k].ref))) return r;
             }
-            pairs.push_back(p);
         }
-        uint32_t rootRef = 0; r = node_ref(c, b, 0, pairBase, leafBase, &rootRef); if (r) return r;
-        // triangles in leaf order + shading records in triIdx order
-        for (uint32_t j = 0; j < b.triCount; j++) {
+        uint32_t rootRef = 0; if ((r = ref_of(0, &rootRef))) return r;
+        // `remain` of every leaf slot: triangles left in its leaf including itself
+        std::vector<uint32_t> remain(b.triCount, 1u);
+        for (uint32_t n = 0; n < b.nodesUsed; n++) {
+            const crt_bvh_node& nd = b.nodes[n];
+            if (nd.triCount == 0) continue;
+            for (uint32_t i = 0; i < nd.triCount; i++) remain[nd.leftFirst + i] = nd.triCount - i;
+        }
+        for (uint32_t j = 0; j < b.triCount; j++) {                       // leaf order: triangleIndices resolved here
             const uint32_t ti = b.triangleIndices[j];
             if (ti >= b.triCount) return c->fail(CRT_ERR_INVALID, "BVH %u: triangleIndices[%u] out of range", bi, j);
             const crt_tri& t = b.triangles[ti];
-            crt::LeafTri lt; memset(&lt, 0, sizeof(lt));
+            crt::LeafTri& lt = leaf[triBase + j];
             for (int k = 0; k < 3; k++) { lt.v0[k] = t.vertex0[k]; lt.e1[k] = t.vertex1[k] - t.vertex0[k]; lt.e2[k] = t.vertex2[k] - t.vertex0[k]; }
-            lt.triIdx = ti;
+            lt.shadeIdx = (uint32_t)(triBase + ti);
             lt.objIdx = (sd->kind == CRT_SCENE_TLAS) ? b.objIdx : t.objIdx;
+            lt.remain = remain[j];
             if (sd->kind == CRT_SCENE_FILE && (t.objIdx < 2 || (uint32_t)(t.objIdx - 2) >= sd->objCount))
                 return c->fail(CRT_ERR_INVALID, "triangle %u: objIdx %d has no entry in objMatIdx", ti, t.objIdx);
-            leaf.push_back(lt);
         }
-        for (uint32_t ti = 0; ti < b.triCount; ti++) {
+        for (uint32_t ti = 0; ti < b.triCount; ti++) {                    // shading records in the reference's triIdx order
             const crt_tri& t = b.triangles[ti];
-            crt::ShadeTri s; memset(&s, 0, sizeof(s));
+            crt::ShadeTri& s = shade[triBase + ti];
             memcpy(s.n0, t.normal0, 12); memcpy(s.n1, t.normal1, 12); memcpy(s.n2, t.normal2, 12);
             memcpy(s.uv0, t.uv0, 8); memcpy(s.uv1, t.uv1, 8); memcpy(s.uv2, t.uv2, 8);
-            s.objIdx = t.objIdx;
-            shade.push_back(s);
+            // materials[models[tri.objIdx - 2]->matIdx] (file_scene.cpp:207) / materials[blas->matIdx] (tlas_file_scene.cpp:240); +2: [0] light, [1] floor
+            s.mat = 2 + ((sd->kind == CRT_SCENE_TLAS) ? b.matIdx : sd->objMatIdx[t.objIdx - 2]);
         }
         if (sd->kind == CRT_SCENE_TLAS) {
-            if (b.objIdx != (int)bi + 2) return c->fail(CRT_ERR_INVALID, "BLAS %u: objIdx must be %u (TLASFileScene numbers objects from 2, tlas_file_scene.cpp:13,51-53)", bi, bi + 2);
-            crt::Instance in; memset(&in, 0, sizeof(in));
+            crt::Instance& in = inst[bi];
             memcpy(in.invT, b.invT, 48); memcpy(in.T, b.T, 48);
-            in.shadeBase = shadeBase; in.matIdx = b.matIdx; in.rootRef = rootRef; in.objIdx = b.objIdx;
-            inst.push_back(in);
-        } else {
-            rootRef0 = rootRef;
-        }
+            in.shadeBase = (uint32_t)triBase; in.mat = 2 + b.matIdx; in.rootRef = rootRef; in.objIdx = b.objIdx;
+        } else rootRef0 = rootRef;
+        pairBase += b.nodesUsed / 2; triBase += b.triCount;
     }
-    std::vector<crt::TlasNode> tlas; uint32_t tlasHeight = 0, tlasRoot = 0;
+    leaf[nTris].remain = 1;                                                 // pad record
+    uint32_t tlasHeight = 0, tlasRoot = 0;
     if (sd->kind == CRT_SCENE_TLAS) {
-        if (sd->tlasNodeCount > 0x7fffu) return c->fail(CRT_ERR_UNSUPPORTED, "TLAS node index exceeds 15 bits");
-        tlas.resize(sd->tlasNodeCount);
         for (uint32_t i = 0; i < sd->tlasNodeCount; i++) {      // device copy carries each node's packed reference instead of leftRight / BLAS
             const crt_tlas_node& nd = sd->tlasNodes[i];
             memcpy(tlas[i].lo, nd.aabbMin, 12); memcpy(tlas[i].hi, nd.aabbMax, 12); tlas[i].pad = 0;
             tlas[i].ref = nd.leftRight ? (crt::kRefTlasInterior | (nd.leftRight & 0x7fffu) | (((nd.leftRight >> 16) & 0x7fffu) << 15))
                                        : (crt::kRefTlasLeaf | (nd.BLAS & 0xffffu));
         }
-        // validate + height
         std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 0u}); size_t visited = 0;
         while (!st.empty()) {
             auto [n, d] = st.back(); st.pop_back();
@@ -307,33 +331,33 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         }
         tlasRoot = tlas[0].ref;
     }
-    // materials: [0] light, [1] floor, then the scene's (file_scene.cpp:10-12, 30-38)
+    // texel pool + materials ([0] light, [1] floor, then the scene's — file_scene.cpp:10-12, 30-38); each carries its texture descriptor
+    std::vector<uint32_t> texOff(sd->textureCount); uint64_t texels = 0;
+    for (uint32_t i = 0; i < sd->textureCount; i++) {
+        texOff[i] = (uint32_t)texels;
+        texels += (uint64_t)sd->textures[i].width * sd->textures[i].height;
+        if (texels > 0xffffffffull) return c->fail(CRT_ERR_UNSUPPORTED, "texture pool exceeds 2^32 texels");
+    }
+    auto bindTex = [&](crt::Material& m, int t) {
+        if (t < 0) { m.texOffset = 0; m.texW = 0; m.texH = 0; }
+        else { m.texOffset = texOff[t]; m.texW = sd->textures[t].width; m.texH = sd->textures[t].height; }
+    };
     std::vector<crt::Material> mats(2 + sd->materialCount);
     memset(mats.data(), 0, mats.size() * sizeof(crt::Material));
-    mats[0].isLight = 1; mats[0].tex = -1;
-    mats[1].tex = sd->floorTexture;
+    bindTex(mats[0], -1);
+    bindTex(mats[1], sd->floorTexture);
     for (uint32_t i = 0; i < sd->materialCount; i++) {
         crt::Material& m = mats[2 + i];
         m.reflectivity = sd->materials[i].reflectivity; m.refractivity = sd->materials[i].refractivity;
-        memcpy(m.absorption, sd->materials[i].absorption, 12); m.tex = sd->materials[i].texture < 0 ? -1 : sd->materials[i].texture;
+        memcpy(m.absorption, sd->materials[i].absorption, 12);
+        bindTex(m, sd->materials[i].texture);
     }
-    std::vector<int32_t> objMat;
-    if (sd->kind == CRT_SCENE_FILE) {
-        if (!sd->objMatIdx || sd->objCount == 0) return c->fail(CRT_ERR_INVALID, "CRT_SCENE_FILE needs objMatIdx");
-        objMat.assign(sd->objMatIdx, sd->objMatIdx + sd->objCount);
-        for (int32_t m : objMat) if (m < 0 || m >= (int)sd->materialCount) return c->fail(CRT_ERR_INVALID, "objMatIdx entry out of range");
-    }
-    // texel pool
-    std::vector<crt::TexDesc> tex(sd->textureCount); size_t texels = 0;
-    for (uint32_t i = 0; i < sd->textureCount; i++) {
-        tex[i].offset = (uint32_t)texels; tex[i].w = sd->textures[i].width; tex[i].h = sd->textures[i].height; tex[i].pad = 0;
-        texels += (size_t)sd->textures[i].width * sd->textures[i].height;
-        if (texels > 0xffffffffull) return c->fail(CRT_ERR_UNSUPPORTED, "texture pool exceeds 2^32 texels");
-    }
+
+    c->freeScene();
     uint32_t* dTexels = nullptr;
-    HIPCK(c, hipMalloc((void**)&dTexels, texels * 4)); c->sceneAllocs.push_back(dTexels);
+    HIPCK(c, hipMalloc((void**)&dTexels, (size_t)texels * 4)); c->sceneAllocs.push_back(dTexels);
     for (uint32_t i = 0; i < sd->textureCount; i++)
-        HIPCK(c, hipMemcpyAsync(dTexels + tex[i].offset, sd->textures[i].pixels, (size_t)tex[i].w * tex[i].h * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(dTexels + texOff[i], sd->textures[i].pixels, (size_t)sd->textures[i].width * sd->textures[i].height * 4, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
 
     crt::Scene& s = c->hScene;
@@ -342,18 +366,15 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     s.lightNrm[0] = -sd->lightT[1]; s.lightNrm[1] = -sd->lightT[5]; s.lightNrm[2] = -sd->lightT[9];   // Quad::GetNormal, primitives.h:363-367
     s.lightSize = sd->lightSize;
     memcpy(s.floorN, sd->floorN, 12); s.floorD = sd->floorD; s.floorInvto = sd->floorInvto;
-    s.floorTex = sd->floorTexture; s.skyTex = sd->skyTexture;
+    s.floorMat = mats[1];
+    s.skyOffset = texOff[sd->skyTexture]; s.skyW = sd->textures[sd->skyTexture].width; s.skyH = sd->textures[sd->skyTexture].height;
     s.texels = dTexels;
     int r;
-    if ((r = upload(c, tex, &s.tex))) return r;
+    const char* dGeom = nullptr;
+    if ((r = upload(c, geom, &dGeom))) return r;
+    s.geom = dGeom;
+    s.tlasOff = (uint32_t)tlasOffB; s.instOff = (uint32_t)instOffB; s.shadeOff = (uint32_t)shadeOffB;
     if ((r = upload(c, mats, &s.mats))) return r;
-    if ((r = upload(c, pairs, &s.pairs))) return r;
-    { crt::LeafTri padRec; memset(&padRec, 0, sizeof(padRec)); leaf.push_back(padRec); }   // record fetches read 64 B from a 48-B LeafTri
-    if ((r = upload(c, leaf, &s.leaf))) return r;
-    if ((r = upload(c, shade, &s.shade))) return r;
-    if ((r = upload(c, objMat, &s.objMat))) return r;
-    if ((r = upload(c, tlas, &s.tlas))) return r;
-    if ((r = upload(c, inst, &s.inst))) return r;
     s.rootRef = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot : rootRef0;
     s.bvhStack = maxHeight + 2;
     s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 3 : 0);   // + TLAS pushes + the return marker + slack

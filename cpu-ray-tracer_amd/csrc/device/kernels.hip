@@ -138,7 +138,10 @@ __device__ __forceinline__ float rnd(uint32_t& s)
 struct Hit { float t, u, v; int objIdx, triIdx; };
 struct Cnt { uint32_t rays, primary, interior, leaf, tri, tlas, visits, meshhits; };
 
-__device__ __forceinline__ float4 ld4(const void* p) { return *reinterpret_cast<const float4*>(p); }
+typedef float rec4 __attribute__((ext_vector_type(4)));     // a fetched 16-byte piece of a record (native vector: usable as an asm operand)
+__device__ __forceinline__ rec4 ld4(const void* p) { return *reinterpret_cast<const rec4*>(p); }
+// record fetch: scalar base + 32-bit per-lane byte offset (global_load_dwordx4 v, v_off, s[base:base+1])
+__device__ __forceinline__ rec4 ldg(const char* __restrict__ base, uint32_t byteOff) { return *reinterpret_cast<const rec4*>(base + byteOff); }
 __device__ __forceinline__ bool finite3(f3 v)
 {
     const uint32_t m = 0x7f800000u;
@@ -146,7 +149,7 @@ __device__ __forceinline__ bool finite3(f3 v)
 }
 
 // slab test, infra/bvh.cpp:181-190, with the reference's std::min / std::max operand order (NaN-exact)
-__device__ __forceinline__ float box_exact(float4 lo, float4 hi, f3 O, f3 rD, float tray)
+__device__ __forceinline__ float box_exact(rec4 lo, rec4 hi, f3 O, f3 rD, float tray)
 {
     float tx1 = (lo.x - O.x) * rD.x, tx2 = (hi.x - O.x) * rD.x;
     float tmin = min_std(tx1, tx2), tmax = max_std(tx1, tx2);
@@ -158,21 +161,24 @@ __device__ __forceinline__ float box_exact(float4 lo, float4 hi, f3 O, f3 rD, fl
 }
 // same test with v_min/v_max(3): identical decisions whenever no product is NaN, i.e. whenever all three rD are
 // finite (0 * inf is the only NaN source); the sign of a zero result never reaches a comparison that can tell.
-__device__ __forceinline__ float box_fast(float4 lo, float4 hi, f3 O, f3 rD, float tray)
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float box_fast(rec4 lo, rec4 hi, f3 O, f3 rD, float tray)
 {
     float tx1 = (lo.x - O.x) * rD.x, tx2 = (hi.x - O.x) * rD.x;
     float ty1 = (lo.y - O.y) * rD.y, ty2 = (hi.y - O.y) * rD.y;
     float tz1 = (lo.z - O.z) * rD.z, tz2 = (hi.z - O.z) * rD.z;
-    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
-    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
+    float tmin = vmax3(vmin(tx1, tx2), vmin(ty1, ty2), vmin(tz1, tz2));
+    float tmax = vmin3(vmax(tx1, tx2), vmax(ty1, ty2), vmax(tz1, tz2));
     return (tmax >= tmin && tmin < tray && tmax > 0) ? tmin : 1e30f;
 }
 
-// Möller–Trumbore against one LeafTri, infra/bvh.cpp:203-222 (strict '<' keeps the first of equal hits)
-__device__ __forceinline__ void hit_tri(const LeafTri* __restrict__ leaf, uint32_t slot, f3 O, f3 D, Hit& h)
+// Möller–Trumbore on a fetched LeafTri {a = v0|shadeIdx, b = e1|objIdx, c = e2|remain}, infra/bvh.cpp:203-222
+// (strict '<' keeps the first of equal hits); every early-out of the reference is folded into one predicate
+__device__ __forceinline__ void hit_tri(rec4 a, rec4 b, rec4 c, f3 O, f3 D, Hit& h)
 {
-    const char* p = reinterpret_cast<const char*>(leaf + slot);
-    const float4 a = ld4(p), b = ld4(p + 16), c = ld4(p + 32);
     const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
     const f3 hh = cross3(D, e2);
     const float det = dot3(e1, hh);
@@ -213,9 +219,8 @@ __device__ __forceinline__ void hit_light_floor(const Scene& sc, f3 O, f3 D, Hit
 }
 
 // BLASBVH::Intersect's ray transform (infra/blas_bvh.cpp:376-381): invT rows, SSE summation order (x+y)+(z+w) / (x+y)+z
-__device__ __forceinline__ void to_object_space(const Instance* __restrict__ in, f3 O, f3 D, f3& Oo, f3& Do, f3& rDo)
+__device__ __forceinline__ void to_object_space(rec4 r0, rec4 r1, rec4 r2, f3 O, f3 D, f3& Oo, f3& Do, f3& rDo)
 {
-    const float4 r0 = ld4(in->invT), r1 = ld4(in->invT + 4), r2 = ld4(in->invT + 8);
     Oo = mk3((O.x * r0.x + O.y * r0.y) + (O.z * r0.z + 1.0f * r0.w),
              (O.x * r1.x + O.y * r1.y) + (O.z * r1.z + 1.0f * r1.w),
              (O.x * r2.x + O.y * r2.y) + (O.z * r2.z + 1.0f * r2.w));
@@ -232,13 +237,14 @@ __device__ __forceinline__ void to_object_space(const Instance* __restrict__ in,
 __device__ __forceinline__ void traverse_bvh_seq(const Scene& sc, uint32_t rootRef, f3 O, f3 D, f3 rD, Hit& h, uint32_t* stk, Cnt& cn,
                                                  int& traversed, int& tested)
 {
+    const char* __restrict__ g = sc.geom;
     uint32_t cur = rootRef, sp = 0;
     for (;;) {
         traversed++;
+        const uint32_t off = (cur & kRefOffsetMask) << 4;
         if (cur & kRefInterior) {
             cn.interior++;
-            const char* p = reinterpret_cast<const char*>(sc.pairs + (cur & 0x3fffffffu));
-            const float4 alo = ld4(p), ahi = ld4(p + 16), blo = ld4(p + 32), bhi = ld4(p + 48);
+            const rec4 alo = ldg(g, off), ahi = ldg(g, off + 16), blo = ldg(g, off + 32), bhi = ldg(g, off + 48);
             float d1 = box_exact(alo, ahi, O, rD, h.t), d2 = box_exact(blo, bhi, O, rD, h.t);
             uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
             if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
@@ -246,8 +252,14 @@ __device__ __forceinline__ void traverse_bvh_seq(const Scene& sc, uint32_t rootR
             else { cur = r1; if (d2 != 1e30f) { stk[sp * 64] = r2; sp++; } }
         } else {
             cn.leaf++;
-            const uint32_t first = cur & 0xffffffu, cnt = cur >> 24;
-            for (uint32_t i = 0; i < cnt; i++) { tested++; cn.tri++; hit_tri(sc.leaf, first + i, O, D, h); }
+            uint32_t o = off;
+            for (;;) {
+                const rec4 a = ldg(g, o), b = ldg(g, o + 16), c = ldg(g, o + 32);
+                tested++; cn.tri++;
+                hit_tri(a, b, c, O, D, h);
+                if (asu(c.w) <= 1u) break;
+                o += 48;
+            }
             if (sp == 0) break;
             cur = stk[(--sp) * 64];
         }
@@ -256,6 +268,7 @@ __device__ __forceinline__ void traverse_bvh_seq(const Scene& sc, uint32_t rootR
 
 __device__ __forceinline__ void find_nearest_seq(const Scene& sc, f3 O, f3 D, f3 rD, Hit& h, uint32_t* stk, Cnt& cn, int& traversed, int& tested)
 {
+    const char* __restrict__ g = sc.geom;
     cn.rays++;
     hit_light_floor(sc, O, D, h);
     if (sc.kind == 0) {
@@ -267,15 +280,15 @@ __device__ __forceinline__ void find_nearest_seq(const Scene& sc, f3 O, f3 D, f3
             traversed++; cn.tlas++;
             if ((cur & kRefTlasLeaf) == kRefTlasLeaf) {
                 cn.visits++;
-                const Instance* in = sc.inst + (cur & 0xffffu);
-                f3 Oo, Do, rDo; to_object_space(in, O, D, Oo, Do, rDo);
-                traverse_bvh_seq(sc, in->rootRef, Oo, Do, rDo, h, stk, cn, traversed, tested);
+                const uint32_t io = sc.instOff + (cur & 0xffffu) * 128u;
+                const rec4 r0 = ldg(g, io), r1 = ldg(g, io + 16), r2 = ldg(g, io + 32), ids = ldg(g, io + 48);
+                f3 Oo, Do, rDo; to_object_space(r0, r1, r2, O, D, Oo, Do, rDo);
+                traverse_bvh_seq(sc, asu(ids.z), Oo, Do, rDo, h, stk, cn, traversed, tested);
                 if (sp == 0) break;
                 cur = tstk[(--sp) * 64];
             } else {
-                const char* p1 = reinterpret_cast<const char*>(sc.tlas + (cur & 0x7fffu));
-                const char* p2 = reinterpret_cast<const char*>(sc.tlas + ((cur >> 15) & 0x7fffu));
-                const float4 alo = ld4(p1), ahi = ld4(p1 + 16), blo = ld4(p2), bhi = ld4(p2 + 16);
+                const uint32_t o1 = sc.tlasOff + (cur & 0x7fffu) * 32u, o2 = sc.tlasOff + ((cur >> 15) & 0x7fffu) * 32u;
+                const rec4 alo = ldg(g, o1), ahi = ldg(g, o1 + 16), blo = ldg(g, o2), bhi = ldg(g, o2 + 16);
                 float d1 = box_exact(alo, ahi, O, rD, h.t), d2 = box_exact(blo, bhi, O, rD, h.t);
                 uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
                 if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
@@ -288,14 +301,13 @@ __device__ __forceinline__ void find_nearest_seq(const Scene& sc, f3 O, f3 D, f3
 }
 
 // Texture::Sample, template/texture.h:61-96
-__device__ __forceinline__ f3 tex_sample(const Scene& sc, int id, float u, float v)
+__device__ __forceinline__ f3 tex_sample(const Scene& sc, uint32_t offset, int w, int hgt, float u, float v)
 {
-    const TexDesc td = sc.tex[id];
     u = clamp_tm(u, 0.0f, 1.0f);
     v = 1 - clamp_tm(v, 0.0f, 1.0f);
-    int x = (int)(u * td.w), y = (int)(v * td.h);
-    x = clampi(x, 0, td.w - 1); y = clampi(y, 0, td.h - 1);
-    uint32_t p = sc.texels[(size_t)td.offset + (size_t)x + (size_t)y * (size_t)td.w];
+    int x = (int)(u * w), y = (int)(v * hgt);
+    x = clampi(x, 0, w - 1); y = clampi(y, 0, hgt - 1);
+    const uint32_t p = sc.texels[offset + (uint32_t)x + (uint32_t)y * (uint32_t)w];
     const float s = 1 / 255.0f;
     return mk3(((p >> 16) & 0xFF) * s, ((p >> 8) & 0xFF) * s, (p & 0xFF) * s);
 }
@@ -305,20 +317,20 @@ __device__ __forceinline__ f3 sky_color(const Scene& sc, f3 D)
 {
     float phi = crt_atan2f(-D.z, D.x) + CRT_PI;
     float theta = crt_acosf(-D.y);
-    return tex_sample(sc, sc.skyTex, phi * CRT_INV2PI, theta * CRT_INVPI);
+    return tex_sample(sc, sc.skyOffset, sc.skyW, sc.skyH, phi * CRT_INV2PI, theta * CRT_INVPI);
 }
 
-// One bounce of Renderer::Sample ("3. PathTracer/renderer.cpp":50-100) after FindNearest.
-// Returns true when the path ends (L = terminal radiance); otherwise writes the throughput factor of this
-// depth and the continuation ray.
-__device__ __forceinline__ bool shade(const Scene& sc, const Hit& h, f3& O, f3& D, f3& rD, bool& inside,
-                                      int depth, uint32_t& seed, f3& factor, f3& L)
+// One bounce of Renderer::Sample ("3. PathTracer/renderer.cpp":50-100) after FindNearest.  (s0..s3) = the hit
+// triangle's ShadeTri, fetched when the traversal finished.  Returns true when the path ends (L = terminal radiance);
+// otherwise writes the throughput factor of this depth and the continuation ray.
+__device__ __forceinline__ bool shade(const Scene& sc, const Hit& h, rec4 s0, rec4 s1, rec4 s2, rec4 s3,
+                                      f3& O, f3& D, f3& rD, bool& inside, int depth, uint32_t& seed, f3& factor, f3& L)
 {
     if (h.objIdx == -1) { L = sky_color(sc, D); return true; }
     if (depth >= sc.depthLimit) { L = mk3(0, 0, 0); return true; }
     if (h.objIdx == 0) { L = mk3(24, 24, 22); return true; }        // light: GetLightColor (file_scene.cpp:164-167)
     f3 I = O + h.t * D;
-    f3 N; float tu = 0, tv = 0; int mat;
+    f3 N; float tu = 0, tv = 0; Material m;
     if (h.objIdx == 1) {                                              // floor: Plane::GetNormal / GetUV (primitives.h:112-133)
         N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
         if (N.y == 1) {
@@ -326,32 +338,30 @@ __device__ __forceinline__ bool shade(const Scene& sc, const Hit& h, f3& O, f3& 
             u *= sc.floorInvto; v *= sc.floorInvto;
             tu = u - __builtin_floorf(u); tv = v - __builtin_floorf(v);
         }
-        mat = 1;
+        m = sc.floorMat;
     } else {                                                          // mesh: GetNormal / GetUV (bvh.cpp:290-305, blas_bvh.cpp:391-406)
-        uint32_t base = 0; const Instance* in = nullptr;
-        if (sc.kind != 0) { in = sc.inst + (h.objIdx - 2); base = in->shadeBase; }
-        const char* p = reinterpret_cast<const char*>(sc.shade + base + (uint32_t)h.triIdx);
-        float4 a = ld4(p), b = ld4(p + 16), c = ld4(p + 32), d = ld4(p + 48);
-        f3 n0 = mk3(a.x, a.y, a.z), n1 = mk3(a.w, b.x, b.y), n2 = mk3(b.z, b.w, c.x);
-        float w = 1 - h.u - h.v;
-        f3 Nn = w * n0 + h.u * n1 + h.v * n2;
-        tu = w * c.y + h.u * c.w + h.v * d.y;
-        tv = w * c.z + h.u * d.x + h.v * d.z;
+        const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+        const float w = 1 - h.u - h.v;
+        const f3 Nn = w * n0 + h.u * n1 + h.v * n2;
+        tu = w * s2.y + h.u * s2.w + h.v * s3.y;
+        tv = w * s2.z + h.u * s3.x + h.v * s3.z;
+        const rec4* mp = reinterpret_cast<const rec4*>(sc.mats + (int)asu(s3.w));
+        const rec4 m0 = mp[0], m1 = mp[1];
+        m.reflectivity = m0.x; m.refractivity = m0.y; m.absorption[0] = m0.z; m.absorption[1] = m0.w; m.absorption[2] = m1.x;
+        m.texOffset = asu(m1.y); m.texW = (int)asu(m1.z); m.texH = (int)asu(m1.w);
         if (sc.kind == 0) {
             N = normalize3(Nn);
-            mat = sc.objMat[(int)asu(d.w) - 2] + 2;
         } else {
-            float4 r0 = ld4(in->T), r1 = ld4(in->T + 4), r2 = ld4(in->T + 8);
+            const uint32_t io = sc.instOff + (uint32_t)(h.objIdx - 2) * 128u + 64u;   // Instance::T rows
+            const rec4 r0 = ldg(sc.geom, io), r1 = ldg(sc.geom, io + 16), r2 = ldg(sc.geom, io + 32);
             f3 Nt = mk3(r0.x * Nn.x + r0.y * Nn.y + r0.z * Nn.z + r0.w * 0.0f,
                         r1.x * Nn.x + r1.y * Nn.y + r1.z * Nn.z + r1.w * 0.0f,
                         r2.x * Nn.x + r2.y * Nn.y + r2.z * Nn.z + r2.w * 0.0f);
             N = normalize3(Nt);
-            mat = in->matIdx + 2;
         }
     }
     if (dot3(N, D) > 0) N = -N;
-    const Material m = sc.mats[mat];
-    f3 albedo = (m.tex >= 0) ? tex_sample(sc, m.tex, tu, tv) : mk3(1.0f, 1.0f, 1.0f);
+    f3 albedo = (m.texW > 0) ? tex_sample(sc, m.texOffset, m.texW, m.texH, tu, tv) : mk3(1.0f, 1.0f, 1.0f);
     f3 medium = mk3(1, 1, 1);
     if (inside) {
         f3 ab = mk3(m.absorption[0], m.absorption[1], m.absorption[2]) * -h.t;
@@ -393,7 +403,6 @@ __device__ __forceinline__ bool shade(const Scene& sc, const Hit& h, f3& O, f3& 
     return false;
 }
 
-
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -406,16 +415,17 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 //
 // Per-lane traversal state is ONE packed reference `cur` (layout.h), the 64-byte record it names — already
 // PRE-LOADED into registers q0..q3 by the trip that produced it — and a stack whose top lives in a register:
-//     cur == 0 (done)      -> SHADE phase: shade the hit (or end the path: unwind, write the sample, generate the next
-//                             pixel's primary ray), start FindNearest for the new ray (quad, plane), cur = root
+//     cur == 0 (done)      -> SHADE phase: shade the hit with the pre-loaded ShadeTri (or end the path: unwind, write the
+//                             sample, generate the next pixel's primary ray), start FindNearest for the new ray (quad,
+//                             plane), cur = root
 //     BVH interior         -> NODE phase: two slab tests on the pre-loaded NodePair, ordered descend / push / pop
 //     BVH leaf             -> TRI phase: ONE Möller–Trumbore test on the pre-loaded LeafTri, next triangle or pop
 //     TLAS interior / leaf -> TLAS phase (two-level scenes): two slab tests on the pre-loaded child nodes / enter the
 //                             BLAS through the pre-loaded invT rows
 // One trip of the wave's loop = ballot the states, run each phase that has enough lanes (thresholds below; a phase
-// always runs when nothing else can), then issue the record loads for every lane that moved.  The loads fly while
-// the next trip's ballots and the other phases' arithmetic execute, so the dependent-fetch latency of the pointer
-// chase is overlapped even when the wave is alone on its SIMD, and a lane only ever pays for its own ray's length.
+// always runs when nothing else can), then issue the record loads for every lane that moved: four 16-byte loads at
+// `geom + 32-bit offset`.  The loads fly while the next trip's ballots and the other phases' arithmetic execute, and a
+// lane only ever pays for its own ray's length, never for the longest ray in the wave.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef CRT_SHADE_BATCH
 #define CRT_SHADE_BATCH 24
@@ -442,6 +452,7 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     uint32_t* stk = lds + lane;
+    const char* __restrict__ geom = sc.geom;
 
     Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
     uint32_t trips = 0;
@@ -467,16 +478,17 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
     Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
     f3 F0 = camPos, F1 = camPos, F2 = camPos, F3 = camPos, F4 = camPos;    // throughput factors of depths 0..4
     // traversal state; (tO, tD, trD) = ray in the space of the structure being walked (object space inside a BLAS)
-    uint32_t cur = kRefDone, sp = 0, tos = 0;                                 // sp counts entries including the register-held top
+    uint32_t cur = kRefDone, sp = 0;
     f3 tO = camPos, tD = camPos, trD = camPos;
     bool rayFinite = true;                                                    // all of trD finite -> v_min/v_max slab test is exact
     bool fresh = true;                                                        // true: SHADE phase must generate a primary ray
-    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;           // pre-loaded record of `cur`
+    rec4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;                        // pre-loaded record of `cur`
 
-#define CRT_PUSH(x) do { if (sp) stk[(sp - 1u) * 64u] = tos; tos = (x); sp++; } while (0)
-#define CRT_POP(dst) do { if (sp) { (dst) = tos; sp--; if (sp) tos = stk[(sp - 1u) * 64u]; } else (dst) = kRefDone; } while (0)
-    // pop for the BVH phases: the return marker switches back to the world-space ray and pops the TLAS entry below it
-#define CRT_POP_BVH(dst) do { CRT_POP(dst); if (KIND == 1 && (dst) == kRefReturn) { tO = O; tD = D; trD = rD; rayFinite = finite3(rD); CRT_POP(dst); } } while (0)
+    // Traversal stack: one LDS column per lane, entry i at stk[i * 64]; `sp` = number of entries.  The hot phases are
+    // written branch-free: the current top is read speculatively at the start of a phase (it arrives while the slab /
+    // triangle arithmetic runs), a push always stores to slot sp (a dead store when the far child was missed) and
+    // only the pointer moves under a select.
+#define CRT_TOP() (stk[(sp ? sp - 1u : 0u) * 64u])
 
     for (;;) {
         const bool isDone = live && cur == kRefDone;
@@ -492,6 +504,10 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
         const bool runTri = nTri >= CRT_TRI_BATCH || (nTri > 0 && nNode + nTlas == 0);
         const bool runShade = nDone >= CRT_SHADE_BATCH || (nDone > 0 && !runNode && !runTlas && !runTri);
         bool moved = false;
+        // The record loads issued at the end of the previous trip are first needed here.  Naming all four tuples in one
+        // empty asm keeps the register allocator from splitting a loaded tuple across the back-edge (it otherwise copies one
+        // component right behind the loads, which puts a vmcnt wait — the whole fetch latency — at the end of every trip).
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
 #ifdef CRT_STAMPS
         CRT_STAMP(s0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -506,7 +522,7 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
             if (!fresh) {
                 if (h.objIdx >= 2) cn.meshhits++;
                 f3 factor, L;
-                const bool done = shade(sc, h, O, D, rD, inside, depth, seed, factor, L);
+                const bool done = shade(sc, h, q0, q1, q2, q3, O, D, rD, inside, depth, seed, factor, L);
                 if (!done) {
                     if (depth == 0) F0 = factor; else if (depth == 1) F1 = factor; else if (depth == 2) F2 = factor;
                     else if (depth == 3) F3 = factor; else F4 = factor;
@@ -518,7 +534,8 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
                     if (depth > 2) L = F2 * L;
                     if (depth > 1) L = F1 * L;
                     if (depth > 0) L = F0 * L;
-                    const uint32_t pix = item / passes, pass = item - pix * passes;
+                    uint32_t pix = item, pass = 0;
+                    if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
                     slab[((size_t)tl * 256u + pix) * S + (size_t)lane * passes + pass] = make_float4(L.x, L.y, L.z, 0.0f);
                     item++;
                     gen = true;
@@ -526,7 +543,7 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
                 }
             }
             if (gen) {
-                const uint32_t pix = item / passes;
+                const uint32_t pix = (passes == 1u) ? item : item / passes;
                 const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
                 const float jy = rnd(seed);                                       // pinned: first draw is the y jitter
                 const float jx = rnd(seed);
@@ -555,23 +572,21 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
             uint32_t next;
             if ((cur & kRefInterior) != 0u) {
                 // TLAS leaf: enter the BLAS (BLASBVH::Intersect, blas_bvh.cpp:376-381): object-space ray through the
-                // pre-loaded invT rows (SSE summation order), return marker on the stack, BLAS root
+                // pre-loaded invT rows, return marker on the stack, BLAS root
                 if (COUNT) cn.visits++;
-                const f3 Oo = mk3((O.x * q0.x + O.y * q0.y) + (O.z * q0.z + 1.0f * q0.w),
-                                  (O.x * q1.x + O.y * q1.y) + (O.z * q1.z + 1.0f * q1.w),
-                                  (O.x * q2.x + O.y * q2.y) + (O.z * q2.z + 1.0f * q2.w));
-                const f3 Do = mk3((D.x * q0.x + D.y * q0.y) + D.z * q0.z,
-                                  (D.x * q1.x + D.y * q1.y) + D.z * q1.z,
-                                  (D.x * q2.x + D.y * q2.y) + D.z * q2.z);
-                tO = Oo; tD = Do; trD = mk3(1 / Do.x, 1 / Do.y, 1 / Do.z); rayFinite = finite3(trD);
-                CRT_PUSH(kRefReturn);
+                to_object_space(q0, q1, q2, O, D, tO, tD, trD);
+                rayFinite = finite3(trD);
+                stk[sp * 64u] = kRefReturn; sp++;
                 next = asu(q3.z);                                                 // Instance::rootRef
             } else {
+                const uint32_t top = CRT_TOP();
                 float d1 = box_exact(q0, q1, tO, trD, h.t), d2 = box_exact(q2, q3, tO, trD, h.t);
                 uint32_t r1 = asu(q0.w), r2 = asu(q2.w);
                 if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
-                if (d1 == 1e30f) CRT_POP(next);
-                else { next = r1; if (d2 != 1e30f) CRT_PUSH(r2); }
+                stk[sp * 64u] = r2;
+                const bool hitN = d1 != 1e30f, push = hitN && d2 != 1e30f, pop = !hitN && sp != 0u;
+                next = hitN ? r1 : (pop ? top : kRefDone);
+                sp = sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
             }
             if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
             cur = next; moved = true;
@@ -584,14 +599,23 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
             const bool allFinite = __ballot(isNode && !rayFinite) == 0ull;
             if (isNode) {
                 if (COUNT) cn.interior++;
+                uint32_t top = CRT_TOP();                                            // speculative: lands during the slab arithmetic
                 float d1, d2;
                 if (allFinite) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
                 else { d1 = box_exact(q0, q1, tO, trD, h.t); d2 = box_exact(q2, q3, tO, trD, h.t); }
-                uint32_t r1 = asu(q0.w), r2 = asu(q2.w);
-                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
-                uint32_t next;
-                if (d1 == 1e30f) CRT_POP_BVH(next);
-                else { next = r1; if (d2 != 1e30f) CRT_PUSH(r2); }
+                const bool sw = d1 > d2;                                             // near child first (strict >: ties keep child 1)
+                const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
+                const uint32_t rn = sw ? asu(q2.w) : asu(q0.w), rf = sw ? asu(q0.w) : asu(q2.w);
+                stk[sp * 64u] = rf;                                                  // dead store unless `push`
+                const bool hitN = dn != 1e30f, push = hitN && df != 1e30f;
+                bool pop = !hitN && sp != 0u;
+                uint32_t next = hitN ? rn : (pop ? top : kRefDone);
+                sp = sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
+                if (KIND == 1 && next == kRefReturn) {                               // BLAS finished: back to the world-space ray, pop the TLAS entry below
+                    tO = O; tD = D; trD = rD; rayFinite = finite3(rD);
+                    pop = sp != 0u; top = CRT_TOP();
+                    next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
+                }
                 if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
                 cur = next; moved = true;
             }
@@ -602,52 +626,42 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4
         if (runTri && isTri) {
             // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:203-222, 232-243) -----------
             if (COUNT) cn.tri++;
-            {
-                const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
-                const f3 hh = cross3(tD, e2);
-                const float det = dot3(e1, hh);
-                const float f = 1 / det;
-                const f3 s = tO - v0;
-                const float u = f * dot3(s, hh);
-                const f3 q = cross3(s, e1);
-                const float v = f * dot3(tD, q);
-                const float t = f * dot3(e2, q);
-                const bool ok = !(det > -0.0001f && det < 0.0001f) && !(u < 0 || u > 1) && !(v < 0 || u + v > 1) && (t > 0.0001f) && (t < h.t);
-                if (ok) { h.t = t; h.u = u; h.v = v; h.triIdx = (int)asu(q0.w); h.objIdx = (int)asu(q1.w); }
+            uint32_t top = CRT_TOP();                                                // speculative, as in the NODE phase
+            hit_tri(q0, q1, q2, tO, tD, h);
+            const bool more = asu(q2.w) > 1u;                                        // next LeafTri of this leaf (48 B = 3 units)
+            bool pop = !more && sp != 0u;
+            uint32_t next = more ? cur + 3u : (pop ? top : kRefDone);
+            sp -= pop ? 1u : 0u;
+            if (KIND == 1 && next == kRefReturn) {
+                tO = O; tD = D; trD = rD; rayFinite = finite3(rD);
+                pop = sp != 0u; top = CRT_TOP();
+                next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
             }
-            uint32_t next;
-            if ((cur >> 24) > 1u) next = cur - 0x01000000u + 1u;                     // count - 1, slot + 1
-            else {
-                CRT_POP_BVH(next);
-                if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
-            }
+            if (COUNT && !more && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
             cur = next; moved = true;
         }
 #ifdef CRT_STAMPS
         CRT_STAMP(s5); stT[3] += s5 - s4;
 #endif
         // ---------------- issue the record loads of every lane that moved (consumed by a later trip) ---------------
-        if (moved && live && cur != kRefDone) {
-            const char* pa; const char* pb;
-            if ((cur & kRefTlasBit) == 0u) {
-                if (cur & kRefInterior) pa = reinterpret_cast<const char*>(sc.pairs + (cur & 0x3fffffffu));
-                else pa = reinterpret_cast<const char*>(sc.leaf + (cur & 0xffffffu));
-                pb = pa + 32;
-            } else if (cur & kRefInterior) {                                         // TLAS leaf: Instance {invT rows, ids}
-                pa = reinterpret_cast<const char*>(sc.inst + (cur & 0xffffu)); pb = pa + 32;
-            } else {                                                                 // TLAS interior: the two child nodes
-                pa = reinterpret_cast<const char*>(sc.tlas + (cur & 0x7fffu));
-                pb = reinterpret_cast<const char*>(sc.tlas + ((cur >> 15) & 0x7fffu));
+        {
+            const bool doneNow = cur == kRefDone;
+            uint32_t oa = doneNow ? sc.shadeOff + (uint32_t)h.triIdx * 64u : (cur & kRefOffsetMask) << 4;   // ShadeTri of the hit | NodePair / LeafTri
+            uint32_t ob = oa + 32u;
+            if (KIND == 1 && !doneNow && (cur & kRefTlasBit) != 0u) {
+                if (cur & kRefInterior) { oa = sc.instOff + (cur & 0xffffu) * 128u; ob = oa + 32u; }                // TLAS leaf: Instance {invT rows, ids}
+                else { oa = sc.tlasOff + (cur & 0x7fffu) * 32u; ob = sc.tlasOff + ((cur >> 15) & 0x7fffu) * 32u; } // TLAS interior: the two child nodes
             }
-            q0 = ld4(pa); q1 = ld4(pa + 16); q2 = ld4(pb); q3 = ld4(pb + 16);
+            // unconditional on purpose: a lane that did not move re-fetches its record (an L1 hit) and a lane with nothing to
+            // fetch reads record 0, so q0..q3 are plain loop-carried load results and nothing has to wait for them here
+            if (!live || (doneNow && h.objIdx < 2)) { oa = 0u; ob = 32u; }
+            q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, ob); q3 = ldg(geom, ob + 16u);
         }
 #ifdef CRT_STAMPS
         CRT_STAMP(s6); stT[4] += s6 - s5; stT[5] += s6 - s0;
 #endif
     }
-#undef CRT_PUSH
-#undef CRT_POP
-#undef CRT_POP_BVH
+#undef CRT_TOP
 
     if (COUNT && tileClocks && lane == 0) {                 // instrumentation build only: per-tile wall time + loop trips
         tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
@@ -710,7 +724,9 @@ __global__ __launch_bounds__(64) void find_nearest_kernel(const Scene sc, const 
         Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
         int traversed = 0, tested = 0;
         find_nearest_seq(sc, O, D, rD, h, lds + lane, cn, traversed, tested);
-        HitOut o; o.t = h.t; o.u = h.u; o.v = h.v; o.objIdx = h.objIdx; o.triIdx = h.triIdx; o.traversed = traversed; o.tested = tested;
+        int triIdx = h.triIdx;
+        if (sc.kind != 0 && h.objIdx >= 2) triIdx -= (int)asu(ldg(sc.geom, sc.instOff + (uint32_t)(h.objIdx - 2) * 128u + 48u).x);   // - Instance::shadeBase
+        HitOut o; o.t = h.t; o.u = h.u; o.v = h.v; o.objIdx = h.objIdx; o.triIdx = triIdx; o.traversed = traversed; o.tested = tested;
         hits[i] = o;
     }
     uint32_t vals[8] = {cn.rays, cn.primary, cn.interior, cn.leaf, cn.tri, cn.tlas, cn.visits, cn.meshhits};
