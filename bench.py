@@ -53,6 +53,12 @@ def cpu_baseline(scene_xml, kind, W, H, budget_s=12.0):
         threads = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:                                   # container CPU quota (cgroup v2 "max period"): more threads than that only get throttled
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = max(1, min(threads, int(int(quota) / int(period))))
+    except Exception:
+        pass
     o, _ = orc.load_scene(scene_xml, kind, ASSETS)
     o.renderer_init(W, H)
     o.render(1, threads)                       # warm-up frame (spp 1), also sizes the sample
@@ -66,7 +72,7 @@ def cpu_baseline(scene_xml, kind, W, H, budget_s=12.0):
     dt = (time.perf_counter() - t1) + one
     c = o.counters()
     return {"value": round(c["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "%d frames (spp 2..%d) of the same %dx%d bunny scene, %d threads, %.1f s" % (frames + 1, frames + 2, W, H, threads, dt),
+            "sample": "%d frames (spp 2..%d) of the same %dx%d scene, %d threads (= usable host cores: affinity capped by the cgroup CPU quota), %.1f s" % (frames + 1, frames + 2, W, H, threads, dt),
             "ms_per_frame": round(dt / (frames + 1) * 1e3, 2)}
 
 

@@ -125,3 +125,27 @@ def test_config5_4k_tile_split_property(crt):
         total += cx.accumulator()
         cx.close()
     assert np.array_equal(total, acc)
+
+
+def test_config4_tower_1080p_256spp(crt, orc):
+    """BASELINE config 4: watch-tower.obj FileScene + textures, 1920x1080, 256 spp = 4 launches of 64 frames.
+    1080 is not a multiple of 16: SCRHEIGHT/16 truncates (renderer.cpp:151), rows 1072..1079 stay untouched."""
+    Wt, Ht, S = 1920, 1080, 256
+    hs = crt.HostScene(scene_path("tower_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(Wt, Ht)
+    hs.upload(ctx)
+    ctx.render(1, S, 1)
+    acc = ctx.accumulator()
+    assert ctx.timing()["render_launches"] == 4
+    c = ctx.counters()
+    assert c["primary"] == (Wt // 16) * (Ht // 16) * 256 * S
+    assert np.isfinite(acc).all() and not acc[1072:].any() and acc[:1072, :, :3].any()
+    o, _ = orc.load_scene(scene_path("tower_scene.xml"), 0, ASSETS)
+    o.renderer_init(Wt, Ht)
+    tw = Wt // 16
+    for t in [tw * 5 + 7, tw * 33 + 60, tw * 45 + 58, tw * 66 + 119]:
+        o.clear()
+        o.set_tile_range(t, 1)
+        o.render(S, 1)
+        x0, y0 = (t % tw) * 16, (t // tw) * 16
+        assert np.array_equal(acc[y0:y0 + 16, x0:x0 + 16], o.accumulator()[y0:y0 + 16, x0:x0 + 16]), t

@@ -33,7 +33,7 @@ def _eq_pm0(a, b):
     return np.array_equal(a, b) and not np.isnan(a).any()
 
 
-@pytest.mark.parametrize("xml,kind", [("bunny_scene.xml", 0), ("cube_scene.xml", 0), ("tlas_scene.xml", 1), ("tlas_scene.xml", 0)])
+@pytest.mark.parametrize("xml,kind", [("bunny_scene.xml", 0), ("cube_scene.xml", 0), ("tlas_scene.xml", 1), ("tlas_scene.xml", 0), ("tower_scene.xml", 0)])
 def test_find_nearest_bit_exact(crt, orc, xml, kind):
     hs = crt.HostScene(scene_path(xml), kind, ASSETS)
     ctx = crt.Context(64, 64)
@@ -52,7 +52,8 @@ def test_find_nearest_bit_exact(crt, orc, xml, kind):
         assert gc[k] == oc[k], k
 
 
-@pytest.mark.parametrize("xml,kind,W,H,frames", [("bunny_scene.xml", 0, 128, 96, 3), ("tlas_scene.xml", 1, 128, 96, 2), ("cube_scene.xml", 0, 80, 48, 5)])
+@pytest.mark.parametrize("xml,kind,W,H,frames", [("bunny_scene.xml", 0, 128, 96, 3), ("tlas_scene.xml", 1, 128, 96, 2), ("cube_scene.xml", 0, 80, 48, 5),
+                                                   ("tower_scene.xml", 0, 128, 96, 2)])
 def test_render_matches_oracle(crt, orc, xml, kind, W, H, frames):
     hs = crt.HostScene(scene_path(xml), kind, ASSETS)
     ctx = crt.Context(W, H, collect_stats=True)

@@ -10,7 +10,7 @@ import pytest
 
 from conftest import ASSETS, REPO, scene_path
 
-SCENES = [("bunny_scene.xml", 0), ("cube_scene.xml", 0), ("tlas_scene.xml", 1), ("tlas_scene.xml", 0)]
+SCENES = [("bunny_scene.xml", 0), ("cube_scene.xml", 0), ("tlas_scene.xml", 1), ("tlas_scene.xml", 0), ("tower_scene.xml", 0)]
 
 
 def test_library_exports_every_declared_symbol(crt):
@@ -56,7 +56,7 @@ def test_loaders_match_independent_readers(crt, orc):
         p = os.path.join(ASSETS, m + ".obj")
         for a, b in zip(crt.load_obj(p), orc.read_obj(p)):
             assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), m
-    for f in ("textures/Stylized_Pavement_basecolor.png", "textures/Stylized_Wood_basecolor.tga", "textures/Defuse_wok.png", "sky_gradient.png"):
+    for f in ("textures/Stylized_Pavement_basecolor.png", "textures/Stylized_Wood_basecolor.tga", "textures/Defuse_wok.png", "textures/Wood_Tower_Col.png", "sky_gradient.png"):
         p = os.path.join(ASSETS, f)
         assert np.array_equal(crt.load_image(p), orc.pack_rgb(orc.read_image(p))), f
 
