@@ -31,7 +31,7 @@ class CrtError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("depthLimit", C.c_int32), ("device", C.c_int32),
                 ("tileFirst", C.c_int32), ("tileStride", C.c_int32), ("tileCount", C.c_int32),
-                ("maxFramesPerLaunch", C.c_int32), ("collectStats", C.c_int32)]
+                ("maxFramesPerLaunch", C.c_int32), ("collectStats", C.c_int32), ("renderStreams", C.c_int32)]
 
 
 class CountersS(C.Structure):
@@ -115,9 +115,9 @@ class Context:
     """crt_ctx: one device, one image (or a strided subset of its 16x16 tiles)."""
 
     def __init__(self, width, height, depth_limit=5, device=0, tile_first=0, tile_stride=1, tile_count=-1,
-                 max_frames_per_launch=0, collect_stats=False):
+                 max_frames_per_launch=0, collect_stats=False, render_streams=0):
         self.L = lib()
-        cfg = Config(width, height, depth_limit, device, tile_first, tile_stride, tile_count, max_frames_per_launch, int(collect_stats))
+        cfg = Config(width, height, depth_limit, device, tile_first, tile_stride, tile_count, max_frames_per_launch, int(collect_stats), render_streams)
         h = C.c_void_p()
         rc = self.L.crt_create(C.byref(h), C.byref(cfg))
         if rc != 0:

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -39,7 +40,11 @@ struct crt_ctx {
     uint32_t tileFirst = 0, tileStride = 1, tileCount = 0;
     // device memory
     void* dAccOwned = nullptr; void* dAcc = nullptr;
-    void* dSlab = nullptr; size_t slabBytes = 0;
+    // render lanes: each has its own HIP stream + sample slab, so consecutive 64-frame launches (which are independent:
+    // different spp windows) overlap on the GPU; the ordered accumulate kernels run on the main stream behind events
+    struct Lane { hipStream_t s = nullptr; void* slab = nullptr; size_t bytes = 0; hipEvent_t slabFree = nullptr; bool pendingFree = false; };
+    std::vector<Lane> lanes; uint64_t launchSeq = 0;
+    std::vector<hipEvent_t> doneEvents;
     crt::Scene hScene{};
     crt::Counters* dCounters = nullptr;
     uint32_t* dPixels = nullptr; float* dTileSums = nullptr;
@@ -123,6 +128,10 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
 {
     if (!out || !cfg) { g_createError = "crt_create: null argument"; return CRT_ERR_INVALID; }
     *out = nullptr;
+    // independent launches overlap on several HIP streams; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+    // (default 4) and serialises kernels that share one.  Only effective when the HIP runtime has not initialised yet
+    // (a host that already uses HIP sets the variable itself); never overrides the user's value.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (cfg->width < 16 || cfg->height < 16) { g_createError = "crt_create: width and height must be at least one 16x16 tile"; return CRT_ERR_INVALID; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -136,6 +145,7 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     if (c->cfg.depthLimit < 0) c->cfg.depthLimit = 5;
     if (c->cfg.depthLimit > 5) { g_createError = "crt_create: depthLimit > 5 unsupported (throughput stack holds 5 factors; reference default is 5)"; delete c; return CRT_ERR_UNSUPPORTED; }
     if (c->cfg.maxFramesPerLaunch <= 0 || c->cfg.maxFramesPerLaunch > 64) c->cfg.maxFramesPerLaunch = 64;
+    if (c->cfg.renderStreams < 0) c->cfg.renderStreams = 0;
     c->tilesX = cfg->width / 16; c->tilesY = cfg->height / 16;      // truncating, as renderer.cpp:151
     const int tiles = c->tilesX * c->tilesY;
     int first = cfg->tileFirst, stride = cfg->tileStride <= 0 ? 1 : cfg->tileStride, count = cfg->tileCount;
@@ -188,7 +198,8 @@ void crt_destroy(crt_ctx* c)
     c->freeScene();
     for (auto& ev : c->evPool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (c->dAccOwned) (void)hipFree(c->dAccOwned);
-    if (c->dSlab) (void)hipFree(c->dSlab);
+    for (auto& l : c->lanes) { if (l.s) (void)hipStreamSynchronize(l.s); if (l.slab) (void)hipFree(l.slab); if (l.slabFree) (void)hipEventDestroy(l.slabFree); if (l.s) (void)hipStreamDestroy(l.s); }
+    for (auto e : c->doneEvents) (void)hipEventDestroy(e);
     if (c->dPixels) (void)hipFree(c->dPixels);
     if (c->dTileSums) (void)hipFree(c->dTileSums);
     if (c->dCounters) (void)hipFree(c->dCounters);
@@ -408,31 +419,45 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     if (!c->haveScene) return c->fail(CRT_ERR_STATE, "crt_render before crt_upload_scene");
     if (passes < 1 || passes > 4) return c->fail(CRT_ERR_INVALID, "passes must be 1..4 (the reference's UI range, renderer.cpp:178)");
     HIPCK(c, hipSetDevice(c->cfg.device));
-    // recycle the previous render's events
-    for (auto& ev : c->evRender) c->evPool.push_back(ev);
-    for (auto& ev : c->evAcc) c->evPool.push_back(ev);
-    c->evRender.clear(); c->evAcc.clear();
     if (c->tileCount == 0 || frames == 0) return CRT_OK;
     const uint32_t maxF = (uint32_t)c->cfg.maxFramesPerLaunch;
     const size_t need = (size_t)c->tileCount * 256u * (size_t)maxF * passes * 16u;
-    if (need > c->slabBytes) {
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        if (c->dSlab) { HIPCK(c, hipFree(c->dSlab)); c->dSlab = nullptr; c->slabBytes = 0; }
-        HIPCK(c, hipMalloc(&c->dSlab, need));
-        c->slabBytes = need;
+    if (c->lanes.empty()) {
+        int n = c->cfg.renderStreams;
+        if (n <= 0) n = 4;
+        if (n > 16) n = 16;
+        if (c->cfg.collectStats) n = 1;                       // per-tile clocks of a statistics context describe ONE launch
+        c->lanes.resize((size_t)n);
+        for (auto& l : c->lanes) {
+            HIPCK(c, hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
+            HIPCK(c, hipEventCreateWithFlags(&l.slabFree, hipEventDisableTiming));
+        }
     }
     for (uint32_t f0 = 0; f0 < frames; f0 += maxF) {
         const uint32_t nf = (frames - f0 < maxF) ? frames - f0 : maxF;
+        crt_ctx::Lane& l = c->lanes[(size_t)(c->launchSeq++ % c->lanes.size())];
+        if (need > l.bytes) {
+            HIPCK(c, hipStreamSynchronize(l.s)); HIPCK(c, hipStreamSynchronize(c->stream));
+            if (l.slab) { HIPCK(c, hipFree(l.slab)); l.slab = nullptr; l.bytes = 0; }
+            HIPCK(c, hipMalloc(&l.slab, need));
+            l.bytes = need; l.pendingFree = false;
+        }
+        // the slab may still be read by the accumulate kernel of the launch that used this lane last
+        if (l.pendingFree) HIPCK(c, hipStreamWaitEvent(l.s, l.slabFree, 0));
         EventPair ev; int r;
         if ((r = take_event(c, c->evRender, &ev))) return r;
-        HIPCK(c, hipEventRecord(ev.a, c->stream));
-        HIPCK(c, crt_launch_render(&c->hScene, c->dSlab, c->dCounters, c->dTileClocks, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, c->stream));
-        HIPCK(c, hipEventRecord(ev.b, c->stream));
+        HIPCK(c, hipEventRecord(ev.a, l.s));
+        HIPCK(c, crt_launch_render(&c->hScene, l.slab, c->dCounters, c->dTileClocks, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, l.s));
+        HIPCK(c, hipEventRecord(ev.b, l.s));
+        // ordered accumulation on the main stream (frame order = launch order), behind this launch
+        HIPCK(c, hipStreamWaitEvent(c->stream, ev.b, 0));
         if ((r = take_event(c, c->evAcc, &ev))) return r;
         HIPCK(c, hipEventRecord(ev.a, c->stream));
-        HIPCK(c, crt_launch_accumulate(c->dSlab, c->dAcc, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, (uint32_t)c->cfg.width, nf * passes, c->stream));
+        HIPCK(c, crt_launch_accumulate(l.slab, c->dAcc, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, (uint32_t)c->cfg.width, nf * passes, c->stream));
         HIPCK(c, hipEventRecord(ev.b, c->stream));
+        HIPCK(c, hipEventRecord(l.slabFree, c->stream));
+        l.pendingFree = true;
     }
     return CRT_OK;
 }
@@ -441,7 +466,8 @@ int crt_sync(crt_ctx* c)
 {
     if (!c) return CRT_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->cfg.device));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));          // every render launch is followed by its accumulate on this stream
+    for (auto& l : c->lanes) HIPCK(c, hipStreamSynchronize(l.s));
     return CRT_OK;
 }
 
@@ -520,10 +546,14 @@ int crt_get_timing(crt_ctx* c, crt_timing* out)
     if (!c || !out) return CRT_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    for (auto& l : c->lanes) HIPCK(c, hipStreamSynchronize(l.s));
     memset(out, 0, sizeof(*out));
     for (auto& ev : c->evRender) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->render_kernel_ms += ms; }
     for (auto& ev : c->evAcc) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->resolve_kernel_ms += ms; }
     out->render_launches = (uint32_t)c->evRender.size();
+    for (auto& ev : c->evRender) c->evPool.push_back(ev);      // the figures cover every launch since the previous crt_get_timing
+    for (auto& ev : c->evAcc) c->evPool.push_back(ev);
+    c->evRender.clear(); c->evAcc.clear();
     return CRT_OK;
 }
 

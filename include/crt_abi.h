@@ -101,6 +101,8 @@ typedef struct crt_config {
     int32_t tileFirst, tileStride, tileCount;
     int32_t maxFramesPerLaunch;  /* 0 = default (64): frames rendered per kernel launch = lanes of one wavefront        */
     int32_t collectStats;        /* !=0: kernels also count node iterations / triangle tests / BLAS visits / mesh hits   */
+    int32_t renderStreams;       /* HIP streams (each with its own sample slab) the 64-frame launches rotate over, so that
+                                    independent launches overlap on the GPU; 0 = default (4), 1 = strictly one launch at a time */
 } crt_config;
 
 typedef struct crt_ray { float O[3]; float D[3]; int32_t inside; } crt_ray;
@@ -121,10 +123,11 @@ typedef struct crt_counters {
     uint64_t mesh_hits;       /* H                                                                                   */
 } crt_counters;
 
-typedef struct crt_timing {
-    float render_kernel_ms;   /* Σ duration of the path-tracing kernel launches of the last crt_render (HIP events on the ctx stream) */
-    float resolve_kernel_ms;  /* Σ duration of the ordered accumulate kernels of the last crt_render                 */
-    uint32_t render_launches; /* number of path-tracing kernel launches in the last crt_render                       */
+typedef struct crt_timing {                /* covers every launch since the previous crt_get_timing call                       */
+    float render_kernel_ms;   /* Σ duration of the path-tracing kernel launches (HIP events on the stream each was launched on; launches on
+                                 different render streams overlap, so this sum can exceed wall time)                 */
+    float resolve_kernel_ms;  /* Σ duration of the ordered accumulate kernels                                        */
+    uint32_t render_launches; /* number of path-tracing kernel launches                                              */
     uint32_t reserved;
 } crt_timing;
 
@@ -142,7 +145,9 @@ int  crt_set_camera(crt_ctx* ctx, const float camPos[3], const float topLeft[3],
 
 /* ---- rendering (upper seam: the tile loop of Renderer::Tick) --------------------------------------- */
 /* Renders `frames` consecutive Ticks: frame k uses spp = spp_first + k*passes for its tile seeds
- * (renderer.cpp:120,167) and adds passes samples per pixel into the accumulator in frame order. */
+ * (renderer.cpp:120,167) and adds passes samples per pixel into the accumulator in frame order.
+ * Asynchronous: launches of up to 64 frames rotate over cfg.renderStreams HIP streams and overlap with those of earlier
+ * crt_render calls; the accumulation order is kept by events.  crt_sync / any read waits for everything. */
 int  crt_render(crt_ctx* ctx, uint32_t spp_first, uint32_t frames, uint32_t passes);
 int  crt_sync(crt_ctx* ctx);
 int  crt_clear(crt_ctx* ctx);                                   /* Renderer::ClearAccumulator (renderer.cpp:15-18)    */
