@@ -107,8 +107,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("CRT_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse the N > 1 code path on a one-GPU box
+        local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU path for the product")
     device = local_rank if world > 1 else 0

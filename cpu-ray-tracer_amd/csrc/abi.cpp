@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstddef>
 #include <cstdio>
@@ -14,7 +15,7 @@
 #include <string>
 #include <vector>
 
-extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_resolve(const void*, uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float, hipStream_t);
@@ -50,6 +51,9 @@ struct crt_ctx {
     uint32_t* dPixels = nullptr; float* dTileSums = nullptr;
     unsigned long long* dTileClocks = nullptr;
     std::vector<void*> sceneAllocs;
+    // dispatch-order heuristic: owned tiles that can see the scene's meshes come first (see render_tiles_kernel)
+    float meshLo[3] = {0, 0, 0}, meshHi[3] = {0, 0, 0}; bool orderDirty = true;
+    uint32_t* dTileOrder = nullptr;
     bool haveScene = false;
     uint32_t ldsBytes = 0;
     // timing of the last crt_render
@@ -204,6 +208,7 @@ void crt_destroy(crt_ctx* c)
     if (c->dTileSums) (void)hipFree(c->dTileSums);
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->dTileClocks) (void)hipFree(c->dTileClocks);
+    if (c->dTileOrder) (void)hipFree(c->dTileOrder);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -391,6 +396,14 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 3 : 0);   // + TLAS pushes + the return marker + slack
     c->ldsBytes = s.stackDepth * 64u * 4u;
     if (c->ldsBytes > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "tree height %u (+TLAS %u) needs %u bytes of LDS traversal stack per wave (> 64 KiB)", maxHeight, tlasHeight, c->ldsBytes);
+    // world-space bounds of all meshes (FileScene: root box of the BVH; TLAS: root box of the TLAS) for the dispatch-order heuristic
+    {
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        auto grow = [&](const float* mn, const float* mx) { for (int k = 0; k < 3; k++) { if (mn[k] < lo[k]) lo[k] = mn[k]; if (mx[k] > hi[k]) hi[k] = mx[k]; } };
+        if (sd->kind == CRT_SCENE_TLAS) grow(sd->tlasNodes[0].aabbMin, sd->tlasNodes[0].aabbMax);
+        else grow(sd->bvhs[0].nodes[0].aabbMin, sd->bvhs[0].nodes[0].aabbMax);
+        memcpy(c->meshLo, lo, 12); memcpy(c->meshHi, hi, 12); c->orderDirty = true;
+    }
     c->haveScene = true;
     return CRT_OK;
 }
@@ -400,7 +413,52 @@ int crt_set_camera(crt_ctx* c, const float camPos[3], const float tl[3], const f
     if (!c || !camPos || !tl || !tr || !bl) return CRT_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->cfg.device));
     memcpy(c->hScene.camPos, camPos, 12); memcpy(c->hScene.topLeft, tl, 12); memcpy(c->hScene.topRight, tr, 12); memcpy(c->hScene.bottomLeft, bl, 12);
+    c->orderDirty = true;
     return CRT_OK;      // the Scene block travels by value in every launch's kernel arguments
+}
+
+// Tiles (local indices 0..tileCount) ordered so that those inside the screen-space bounding rectangle of the meshes' world
+// box come first.  Pure scheduling heuristic: the projection uses the pin-hole camera of crt_set_camera in double precision
+// and is conservative on failure (a corner behind the eye makes every tile a candidate).
+static int update_tile_order(crt_ctx* c)
+{
+    if (!c->orderDirty || c->tileCount == 0) return 0;
+    const crt::Scene& s = c->hScene;
+    double R[3], Dn[3], N[3];
+    for (int k = 0; k < 3; k++) { R[k] = (double)s.topRight[k] - s.topLeft[k]; Dn[k] = (double)s.bottomLeft[k] - s.topLeft[k]; }
+    N[0] = R[1] * Dn[2] - R[2] * Dn[1]; N[1] = R[2] * Dn[0] - R[0] * Dn[2]; N[2] = R[0] * Dn[1] - R[1] * Dn[0];
+    const double rr = R[0] * R[0] + R[1] * R[1] + R[2] * R[2], dd = Dn[0] * Dn[0] + Dn[1] * Dn[1] + Dn[2] * Dn[2];
+    double E[3]; for (int k = 0; k < 3; k++) E[k] = (double)s.topLeft[k] - s.camPos[k];
+    const double num = E[0] * N[0] + E[1] * N[1] + E[2] * N[2];
+    double u0 = 1e30, u1 = -1e30, v0 = 1e30, v1 = -1e30; bool all = false;
+    for (int i = 0; i < 8 && !all; i++) {
+        double P[3] = {(i & 1) ? c->meshHi[0] : c->meshLo[0], (i & 2) ? c->meshHi[1] : c->meshLo[1], (i & 4) ? c->meshHi[2] : c->meshLo[2]};
+        double d[3] = {P[0] - s.camPos[0], P[1] - s.camPos[1], P[2] - s.camPos[2]};
+        const double den = d[0] * N[0] + d[1] * N[1] + d[2] * N[2];
+        const double t = den != 0 ? num / den : -1;
+        if (!(t > 0) || rr == 0 || dd == 0) { all = true; break; }
+        double Q[3]; for (int k = 0; k < 3; k++) Q[k] = s.camPos[k] + t * d[k] - s.topLeft[k];
+        const double u = (Q[0] * R[0] + Q[1] * R[1] + Q[2] * R[2]) / rr, v = (Q[0] * Dn[0] + Q[1] * Dn[1] + Q[2] * Dn[2]) / dd;
+        if (u < u0) u0 = u; if (u > u1) u1 = u; if (v < v0) v0 = v; if (v > v1) v1 = v;
+    }
+    int tx0 = 0, tx1 = c->tilesX - 1, ty0 = 0, ty1 = c->tilesY - 1;
+    if (!all) {
+        tx0 = (int)floor(u0 * c->cfg.width / 16.0) - 1; tx1 = (int)floor(u1 * c->cfg.width / 16.0) + 1;
+        ty0 = (int)floor(v0 * c->cfg.height / 16.0) - 1; ty1 = (int)floor(v1 * c->cfg.height / 16.0) + 1;
+    }
+    std::vector<uint32_t> first, rest;
+    for (uint32_t i = 0; i < c->tileCount; i++) {
+        const uint32_t tile = c->tileFirst + i * c->tileStride;
+        const int tx = (int)(tile % (uint32_t)c->tilesX), ty = (int)(tile / (uint32_t)c->tilesX);
+        ((tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) ? first : rest).push_back(i);
+    }
+    first.insert(first.end(), rest.begin(), rest.end());
+    if (!c->dTileOrder) HIPCK(c, hipMalloc((void**)&c->dTileOrder, (size_t)c->tileCount * 4));
+    HIPCK(c, hipStreamSynchronize(c->stream));              // launches in flight still read the previous order
+    for (auto& l : c->lanes) HIPCK(c, hipStreamSynchronize(l.s));
+    HIPCK(c, hipMemcpy(c->dTileOrder, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+    c->orderDirty = false;
+    return 0;
 }
 
 static int take_event(crt_ctx* c, std::vector<EventPair>& list, EventPair* out)
@@ -422,6 +480,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     if (c->tileCount == 0 || frames == 0) return CRT_OK;
     const uint32_t maxF = (uint32_t)c->cfg.maxFramesPerLaunch;
     const size_t need = (size_t)c->tileCount * 256u * (size_t)maxF * passes * 16u;
+    { int r = update_tile_order(c); if (r) return r; }
     if (c->lanes.empty()) {
         int n = c->cfg.renderStreams;
         if (n <= 0) n = 4;
@@ -447,7 +506,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         EventPair ev; int r;
         if ((r = take_event(c, c->evRender, &ev))) return r;
         HIPCK(c, hipEventRecord(ev.a, l.s));
-        HIPCK(c, crt_launch_render(&c->hScene, l.slab, c->dCounters, c->dTileClocks, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+        HIPCK(c, crt_launch_render(&c->hScene, l.slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
                                    spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, l.s));
         HIPCK(c, hipEventRecord(ev.b, l.s));
         // ordered accumulation on the main stream (frame order = launch order), behind this launch

@@ -434,21 +434,27 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 #define CRT_TRI_BATCH 1
 #endif
 
+#ifndef CRT_MIN_WAVES
+#define CRT_MIN_WAVES 4      // waves per SIMD the register budget must allow (<= 128 VGPRs)
+#endif
 template <int KIND, bool COUNT>
-__global__ __launch_bounds__(64) void render_tiles_kernel(const Scene sc, float4* __restrict__ slab,
+__global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const Scene sc, float4* __restrict__ slab,
                                                            Counters* __restrict__ counters, unsigned long long* __restrict__ tileClocks,
+                                                           const uint32_t* __restrict__ tileOrder,
                                                            uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                            uint32_t sppFirst, uint32_t frames, uint32_t passes)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     const unsigned long long clk0 = COUNT ? wall_clock64() : 0ull;
-    // XCD-aware order: blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8); give each XCD a contiguous
-    // run of tiles so neighbouring tiles (same BVH subtrees, same texture rows) share one L2.  Speed only.
-    uint32_t b = blockIdx.x, nb = gridDim.x;
-    uint32_t tl = b;
-    if ((nb & 7u) == 0) tl = (b & 7u) * (nb >> 3) + (b >> 3);
-    if (tl >= tileCount) return;
+    // block -> tile.  The kernel's duration is set by its most expensive tiles (one serial RNG stream per lane), so the host
+    // lists the tiles whose pixels can see the meshes FIRST (tileOrder): the dispatcher starts them first and they are dealt
+    // round-robin over the 8 XCDs / 256 CUs instead of piling up on the XCDs that own the image rows of the model.  The
+    // geometry fits every XCD's L2, so nothing is lost by not giving an XCD a contiguous run of tiles (measured: a
+    // contiguous-per-XCD mapping is 7-14 % slower).  Speed only; any bijection gives the same image.
+    const uint32_t b = blockIdx.x;
+    if (b >= tileCount) return;
+    const uint32_t tl = tileOrder ? tileOrder[b] : b;
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     uint32_t* stk = lds + lane;
@@ -766,13 +772,13 @@ __global__ __launch_bounds__(64) void resolve_kernel(const float4* __restrict__ 
 // ------------------------------------------------------------------------------------------------------------
 // launch wrappers (called from abi.cpp)
 // ------------------------------------------------------------------------------------------------------------
-extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks,
+extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                         uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
                                         uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
     dim3 grid(tileCount), block(64);
-#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileClocks, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes)
+#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH(0, true); else CRT_LAUNCH(0, false); }
     else { if (collectStats) CRT_LAUNCH(1, true); else CRT_LAUNCH(1, false); }
 #undef CRT_LAUNCH

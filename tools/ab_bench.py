@@ -25,11 +25,15 @@ crt = importlib.util.module_from_spec(spec); spec.loader.exec_module(crt)
 A = os.path.join(REPO, "assets")
 xml, kind, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 sc = crt.HostScene(os.path.join(A, "scenes", xml), kind, A)
-ctx = crt.Context(W, H); sc.upload(ctx)
+import time
+ctx = crt.Context(W, H, render_streams=int(os.environ.get("AB_STREAMS", "4"))); sc.upload(ctx)
 ts = []
-for i in range(6):
+for i in range(4):
     ctx.clear(); ctx.render(1, 64, 1); ctx.sync(); ts.append(ctx.timing()["render_kernel_ms"])
-print("%%.3f %%.3f" %% (np.median(ts[1:]), min(ts[1:])))
+ctx.clear(); ctx.sync(); t0 = time.perf_counter()
+for i in range(24): ctx.render(1 + 64 * i, 64, 1)
+ctx.sync(); thr = (time.perf_counter() - t0) / 24 * 1e3
+print("single-launch %%.3f ms | pipelined %%.3f ms/step" %% (np.median(ts[1:]), thr))
 ''' % REPO
     scene = args[0] if args else "bunny_scene.xml"
     kind = args[1] if len(args) > 1 else "0"
@@ -37,9 +41,9 @@ print("%%.3f %%.3f" %% (np.median(ts[1:]), min(ts[1:])))
     H = args[3] if len(args) > 3 else "720"
     for f in sorted(os.listdir(VDIR)):
         if not f.endswith(".so"): continue
-        env = dict(os.environ, CRT_LIB_PATH=os.path.join(VDIR, f))
+        env = dict(os.environ, CRT_LIB_PATH=os.path.join(VDIR, f), GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "8"))
         r = subprocess.run([sys.executable, "-c", child, scene, kind, W, H], env=env, capture_output=True, text=True)
-        print("%-40s median/min kernel ms: %s %s" % (f, r.stdout.strip(), r.stderr.strip()[-200:] if r.returncode else ""))
+        print("%-40s %s %s" % (f, r.stdout.strip(), r.stderr.strip()[-200:] if r.returncode else ""))
 
 if __name__ == "__main__":
     if sys.argv[1] == "build": build(sys.argv[2:])
