@@ -29,7 +29,7 @@ import numpy as np
 
 # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels that share a queue serialise; the
 # back end overlaps independent 64-frame launches on several streams, so give the runtime enough queues BEFORE it initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 ASSETS = os.path.join(REPO, "assets")
@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--scene", default="bunny_scene.xml")
     ap.add_argument("--kind", type=int, default=0, help="0 = FileScene (single BVH), 1 = TLASFileScene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the 64-frame launches rotate over (crt_config.renderStreams)")
+    ap.add_argument("--streams", type=int, default=6, help="HIP streams the 64-frame launches rotate over (crt_config.renderStreams)")
     args = ap.parse_args()
 
     import torch

@@ -135,7 +135,7 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     // independent launches overlap on several HIP streams; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
     // (default 4) and serialises kernels that share one.  Only effective when the HIP runtime has not initialised yet
     // (a host that already uses HIP sets the variable itself); never overrides the user's value.
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     if (cfg->width < 16 || cfg->height < 16) { g_createError = "crt_create: width and height must be at least one 16x16 tile"; return CRT_ERR_INVALID; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -483,7 +483,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     { int r = update_tile_order(c); if (r) return r; }
     if (c->lanes.empty()) {
         int n = c->cfg.renderStreams;
-        if (n <= 0) n = 4;
+        if (n <= 0) n = 6;
         if (n > 16) n = 16;
         if (c->cfg.collectStats) n = 1;                       // per-tile clocks of a statistics context describe ONE launch
         c->lanes.resize((size_t)n);

@@ -26,7 +26,7 @@ A = os.path.join(REPO, "assets")
 xml, kind, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 sc = crt.HostScene(os.path.join(A, "scenes", xml), kind, A)
 import time
-ctx = crt.Context(W, H, render_streams=int(os.environ.get("AB_STREAMS", "4"))); sc.upload(ctx)
+ctx = crt.Context(W, H, render_streams=int(os.environ.get("AB_STREAMS", "6"))); sc.upload(ctx)
 ts = []
 for i in range(4):
     ctx.clear(); ctx.render(1, 64, 1); ctx.sync(); ts.append(ctx.timing()["render_kernel_ms"])
@@ -41,7 +41,7 @@ print("single-launch %%.3f ms | pipelined %%.3f ms/step" %% (np.median(ts[1:]), 
     H = args[3] if len(args) > 3 else "720"
     for f in sorted(os.listdir(VDIR)):
         if not f.endswith(".so"): continue
-        env = dict(os.environ, CRT_LIB_PATH=os.path.join(VDIR, f), GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "8"))
+        env = dict(os.environ, CRT_LIB_PATH=os.path.join(VDIR, f), GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "16"))
         r = subprocess.run([sys.executable, "-c", child, scene, kind, W, H], env=env, capture_output=True, text=True)
         print("%-40s %s %s" % (f, r.stdout.strip(), r.stderr.strip()[-200:] if r.returncode else ""))
 
