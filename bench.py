@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--scene", default="bunny_scene.xml")
     ap.add_argument("--kind", type=int, default=0, help="0 = FileScene (single BVH), 1 = TLASFileScene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=6, help="HIP streams the 64-frame launches rotate over (crt_config.renderStreams)")
+    ap.add_argument("--streams", type=int, default=7, help="HIP streams the 64-frame launches rotate over (crt_config.renderStreams)")
     args = ap.parse_args()
 
     import torch

@@ -395,6 +395,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     s.bvhStack = maxHeight + 2;
     s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 3 : 0);   // + TLAS pushes + the return marker + slack
     c->ldsBytes = s.stackDepth * 64u * 4u;
+    if (const char* e = getenv("CRT_DEBUG_EXTRA_LDS")) c->ldsBytes += (uint32_t)atoi(e);   // occupancy experiments only
     if (c->ldsBytes > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "tree height %u (+TLAS %u) needs %u bytes of LDS traversal stack per wave (> 64 KiB)", maxHeight, tlasHeight, c->ldsBytes);
     // world-space bounds of all meshes (FileScene: root box of the BVH; TLAS: root box of the TLAS) for the dispatch-order heuristic
     {
@@ -483,7 +484,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     { int r = update_tile_order(c); if (r) return r; }
     if (c->lanes.empty()) {
         int n = c->cfg.renderStreams;
-        if (n <= 0) n = 6;
+        if (n <= 0) n = 7;
         if (n > 16) n = 16;
         if (c->cfg.collectStats) n = 1;                       // per-tile clocks of a statistics context describe ONE launch
         c->lanes.resize((size_t)n);

@@ -102,7 +102,7 @@ typedef struct crt_config {
     int32_t maxFramesPerLaunch;  /* 0 = default (64): frames rendered per kernel launch = lanes of one wavefront        */
     int32_t collectStats;        /* !=0: kernels also count node iterations / triangle tests / BLAS visits / mesh hits   */
     int32_t renderStreams;       /* HIP streams (each with its own sample slab) the 64-frame launches rotate over, so that
-                                    independent launches overlap on the GPU; 0 = default (6), 1 = strictly one launch at a time */
+                                    independent launches overlap on the GPU; 0 = default (7), 1 = strictly one launch at a time */
 } crt_config;
 
 typedef struct crt_ray { float O[3]; float D[3]; int32_t inside; } crt_ray;

@@ -26,7 +26,7 @@ A = os.path.join(REPO, "assets")
 xml, kind, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 sc = crt.HostScene(os.path.join(A, "scenes", xml), kind, A)
 import time
-ctx = crt.Context(W, H, render_streams=int(os.environ.get("AB_STREAMS", "6"))); sc.upload(ctx)
+ctx = crt.Context(W, H, render_streams=int(os.environ.get("AB_STREAMS", "7"))); sc.upload(ctx)
 ts = []
 for i in range(4):
     ctx.clear(); ctx.render(1, 64, 1); ctx.sync(); ts.append(ctx.timing()["render_kernel_ms"])
