@@ -493,15 +493,19 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
             HIPCK(c, hipEventCreateWithFlags(&l.slabFree, hipEventDisableTiming));
         }
     }
-    for (uint32_t f0 = 0; f0 < frames; f0 += maxF) {
-        const uint32_t nf = (frames - f0 < maxF) ? frames - f0 : maxF;
-        crt_ctx::Lane& l = c->lanes[(size_t)(c->launchSeq++ % c->lanes.size())];
-        if (need > l.bytes) {
-            HIPCK(c, hipStreamSynchronize(l.s)); HIPCK(c, hipStreamSynchronize(c->stream));
+    // every lane's slab is sized up front (hipMalloc synchronises the device: doing it lazily would serialise the first launches)
+    if (need > c->lanes[0].bytes) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        for (auto& l : c->lanes) {
+            HIPCK(c, hipStreamSynchronize(l.s));
             if (l.slab) { HIPCK(c, hipFree(l.slab)); l.slab = nullptr; l.bytes = 0; }
             HIPCK(c, hipMalloc(&l.slab, need));
             l.bytes = need; l.pendingFree = false;
         }
+    }
+    for (uint32_t f0 = 0; f0 < frames; f0 += maxF) {
+        const uint32_t nf = (frames - f0 < maxF) ? frames - f0 : maxF;
+        crt_ctx::Lane& l = c->lanes[(size_t)(c->launchSeq++ % c->lanes.size())];
         // the slab may still be read by the accumulate kernel of the launch that used this lane last
         if (l.pendingFree) HIPCK(c, hipStreamWaitEvent(l.s, l.slabFree, 0));
         EventPair ev; int r;

@@ -238,3 +238,25 @@ def test_renderer_facade_tick_semantics(crt, orc):
     r.tick(16.0)
     o.clear(); o.set_spp(8); o.set_camera_state((0.5, 0.2, -2.5), (0.0, -0.4, 2.0)); o.render(1, 2)
     assert np.array_equal(r.accumulator(), o.accumulator())
+
+
+@pytest.mark.parametrize("streams", [1, 3, 7])
+def test_back_to_back_renders_keep_frame_order(crt, orc, streams):
+    """many asynchronous crt_render calls (they overlap on `streams` HIP streams) must accumulate in frame order:
+    20 windows of 3 frames, no sync in between, against 60 sequential oracle Ticks"""
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(64, 48, render_streams=streams)
+    hs.upload(ctx)
+    for i in range(20):
+        ctx.render(1 + 3 * i, 3, 1)
+    acc = ctx.accumulator()
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o.renderer_init(64, 48)
+    o.render(60, 4)
+    assert np.array_equal(acc, o.accumulator())
+    assert ctx.counters()["rays"] == o.counters()["rays"]
+    assert ctx.timing()["render_launches"] == 20
+    # a clear between windows is ordered with the accumulates too
+    ctx.render(1, 2, 1); ctx.clear(); ctx.render(1, 2, 1)
+    o.clear(); o.render(2, 2)
+    assert np.array_equal(ctx.accumulator(), o.accumulator())
