@@ -31,8 +31,8 @@ ts = []
 for i in range(4):
     ctx.clear(); ctx.render(1, 64, 1); ctx.sync(); ts.append(ctx.timing()["render_kernel_ms"])
 ctx.clear(); ctx.sync(); t0 = time.perf_counter()
-for i in range(24): ctx.render(1 + 64 * i, 64, 1)
-ctx.sync(); thr = (time.perf_counter() - t0) / 24 * 1e3
+for i in range(56): ctx.render(1 + 64 * i, 64, 1)
+ctx.sync(); thr = (time.perf_counter() - t0) / 56 * 1e3
 print("single-launch %%.3f ms | pipelined %%.3f ms/step" %% (np.median(ts[1:]), thr))
 ''' % REPO
     scene = args[0] if args else "bunny_scene.xml"
