@@ -480,7 +480,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (c->tileCount == 0 || frames == 0) return CRT_OK;
     const uint32_t maxF = (uint32_t)c->cfg.maxFramesPerLaunch;
-    const size_t need = (size_t)c->tileCount * 256u * (size_t)maxF * passes * 16u;
+    const size_t need = (size_t)c->tileCount * 256u * (size_t)(frames < maxF ? frames : maxF) * passes * 16u;   // one launch's samples
     { int r = update_tile_order(c); if (r) return r; }
     if (c->lanes.empty()) {
         int n = c->cfg.renderStreams;
@@ -496,6 +496,17 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     // every lane's slab is sized up front (hipMalloc synchronises the device: doing it lazily would serialise the first launches)
     if (need > c->lanes[0].bytes) {
         HIPCK(c, hipStreamSynchronize(c->stream));
+        for (auto& l : c->lanes) { HIPCK(c, hipStreamSynchronize(l.s)); if (l.slab) { HIPCK(c, hipFree(l.slab)); l.slab = nullptr; l.bytes = 0; } }
+        // never take more than half of the free HBM for slabs: fewer lanes (less overlap) instead of an allocation failure
+        size_t freeB = 0, totalB = 0;
+        HIPCK(c, hipMemGetInfo(&freeB, &totalB));
+        size_t fit = need ? (freeB / 2) / need : c->lanes.size();
+        if (fit < 1) fit = 1;
+        while (c->lanes.size() > fit) {
+            crt_ctx::Lane& l = c->lanes.back();
+            (void)hipEventDestroy(l.slabFree); (void)hipStreamDestroy(l.s);
+            c->lanes.pop_back();
+        }
         for (auto& l : c->lanes) {
             HIPCK(c, hipStreamSynchronize(l.s));
             if (l.slab) { HIPCK(c, hipFree(l.slab)); l.slab = nullptr; l.bytes = 0; }
