@@ -52,13 +52,13 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("objIdx", "<i4"
 
 # every symbol include/crt_abi.h and include/crt_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = ["crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
-               "crt_render", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
+               "crt_render", "crt_whitted_tick", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
                "crt_reset_counters", "crt_get_timing", "crt_get_tile_clocks", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
 HOST_SYMBOLS = ["crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
                 "crt_host_scene_triangle_count", "crt_host_scene_bvh_count", "crt_host_scene_bvh_info", "crt_host_scene_bvh_copy",
                 "crt_host_scene_blas_transform", "crt_host_scene_tlas_copy", "crt_host_camera_state", "crt_host_renderer_create",
                 "crt_host_renderer_destroy", "crt_host_renderer_init", "crt_host_renderer_set_camera", "crt_host_renderer_set_passes",
-                "crt_host_renderer_clear", "crt_host_renderer_tick", "crt_host_renderer_render", "crt_host_renderer_spp",
+                "crt_host_renderer_clear", "crt_host_renderer_tick", "crt_host_renderer_render", "crt_host_renderer_tick_whitted", "crt_host_renderer_spp",
                 "crt_host_renderer_energy", "crt_host_renderer_accumulator", "crt_host_renderer_screen", "crt_host_renderer_ctx",
                 "crt_host_obj_load", "crt_host_image_load", "crt_host_free"]
 
@@ -162,6 +162,11 @@ class Context:
 
     def render(self, spp_first, frames, passes=1):
         self._ck(self.L.crt_render(self.h, C.c_uint32(spp_first), C.c_uint32(frames), C.c_uint32(passes)))
+
+    def whitted_tick(self):
+        px = np.empty((self.H, self.W), np.uint32)
+        self._ck(self.L.crt_whitted_tick(self.h, _p(px)))
+        return px
 
     def sync(self):
         self._ck(self.L.crt_sync(self.h))
@@ -320,6 +325,9 @@ class HostRenderer:
 
     def render(self, frames):
         self._ck(self.L.crt_host_renderer_render(self.h, frames))
+
+    def tick_whitted(self):
+        self._ck(self.L.crt_host_renderer_tick_whitted(self.h))
 
     @property
     def spp(self):

@@ -18,6 +18,7 @@
 extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_whitted(const crt::Scene*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_resolve(const void*, uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float, hipStream_t);
 
 static_assert(sizeof(crt_bvh_node) == 32 && sizeof(crt_tri) == 112 && sizeof(crt_tlas_node) == 32, "reference layouts");
@@ -381,6 +382,13 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     memcpy(s.lightInvT, sd->lightInvT, 48);
     s.lightNrm[0] = -sd->lightT[1]; s.lightNrm[1] = -sd->lightT[5]; s.lightNrm[2] = -sd->lightT[9];   // Quad::GetNormal, primitives.h:363-367
     s.lightSize = sd->lightSize;
+    {   // GetLightPos (file_scene.cpp:156-162): middle of the quad's two corners, 0.01 below; scalar TransformPosition order
+        const float* m = sd->lightT;
+        const float ax = -0.5f, ay = 0.0f, az = -0.5f, bx = 0.5f, by = 0.0f, bz = 0.5f;
+        const float c1[3] = {m[0] * ax + m[1] * ay + m[2] * az + m[3] * 1.0f, m[4] * ax + m[5] * ay + m[6] * az + m[7] * 1.0f, m[8] * ax + m[9] * ay + m[10] * az + m[11] * 1.0f};
+        const float c2[3] = {m[0] * bx + m[1] * by + m[2] * bz + m[3] * 1.0f, m[4] * bx + m[5] * by + m[6] * bz + m[7] * 1.0f, m[8] * bx + m[9] * by + m[10] * bz + m[11] * 1.0f};
+        s.lightPos[0] = (c1[0] + c2[0]) * 0.5f - 0.0f; s.lightPos[1] = (c1[1] + c2[1]) * 0.5f - 0.01f; s.lightPos[2] = (c1[2] + c2[2]) * 0.5f - 0.0f;
+    }
     memcpy(s.floorN, sd->floorN, 12); s.floorD = sd->floorD; s.floorInvto = sd->floorInvto;
     s.floorMat = mats[1];
     s.skyOffset = texOff[sd->skyTexture]; s.skyW = sd->textures[sd->skyTexture].width; s.skyH = sd->textures[sd->skyTexture].height;
@@ -574,6 +582,17 @@ int crt_resolve_screen(crt_ctx* c, float scale, uint32_t* hostPixels, float* ene
     HIPCK(c, hipMemcpyAsync(sums.data(), c->dTileSums, (size_t)tiles * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     if (energy) { float e = 0; for (int i = 0; i < tiles; i++) e += sums[i]; *energy = e; }   // renderer.cpp:155-157, tile order
+    return CRT_OK;
+}
+
+int crt_whitted_tick(crt_ctx* c, uint32_t* hostPixels)
+{
+    if (!c) return CRT_ERR_INVALID;
+    if (!c->haveScene) return c->fail(CRT_ERR_STATE, "crt_whitted_tick before crt_upload_scene");
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, crt_launch_whitted(&c->hScene, c->dAcc, c->dPixels, c->dCounters, c->ldsBytes, c->stream));
+    if (hostPixels) HIPCK(c, hipMemcpyAsync(hostPixels, c->dPixels, (size_t)c->cfg.width * c->cfg.height * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
 }
 

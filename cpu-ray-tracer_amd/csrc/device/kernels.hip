@@ -744,6 +744,211 @@ __global__ __launch_bounds__(64) void find_nearest_kernel(const Scene sc, const 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// whitted_kernel: the reference's second front-end ("2. WhittedStyle/renderer.cpp":21-157) behind the same boundary.
+// Deterministic (no RNG), so one thread per pixel.  Trace()'s recursion (a dielectric spawns a refracted AND a
+// reflected ray) runs on an explicit frame stack in post-order, so every float sum and product happens in the
+// reference's order:  return medium * (((0 + cA*Trace(a)) + cB*Trace(b)) + C).
+// ------------------------------------------------------------------------------------------------------------
+struct WFrame { f3 cA, cB, C, medium, out, bO, bD; int flags; };     // flags: 1 hasA, 2 hasB, 4 hasC, 8 b.inside, 16 waiting for B
+constexpr int kWhittedMaxDepth = 7;
+
+__device__ __forceinline__ bool whitted_occluded(const Scene& sc, f3 O, f3 D, float tmax, uint32_t* stk, Cnt& cn)   // FileScene::IsOccluded, file_scene.cpp:177-187
+{
+    {   // Quad::IsOccluded, primitives.h:347-362
+        const float* c = sc.lightInvT;
+        const float Oy = c[4] * O.x + c[5] * O.y + c[6] * O.z + c[7];
+        const float Dy = c[4] * D.x + c[5] * D.y + c[6] * D.z;
+        const float t = Oy / -Dy;
+        if (t < tmax && t > 0) {
+            const float Ox = c[0] * O.x + c[1] * O.y + c[2] * O.z + c[3];
+            const float Oz = c[8] * O.x + c[9] * O.y + c[10] * O.z + c[11];
+            const float Dx = c[0] * D.x + c[1] * D.y + c[2] * D.z;
+            const float Dz = c[8] * D.x + c[9] * D.y + c[10] * D.z;
+            const float Ix = Ox + t * Dx, Iz = Oz + t * Dz;
+            const float size = sc.lightSize;
+            if (Ix > -size && Ix < size && Iz > -size && Iz < size) return true;
+        }
+    }
+    // shadow.t = 1e34f; acc.Intersect(shadow): a full nearest-hit query over the whole ray (bug-compatible: not clipped at the light)
+    Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+    const f3 rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
+    int traversed = 0, tested = 0;
+    cn.rays++;
+    if (sc.kind == 0) traverse_bvh_seq(sc, sc.rootRef, O, D, rD, h, stk, cn, traversed, tested);
+    else {
+        Hit hh = h; Cnt dummy = cn;
+        // TLAS walk without the quad / plane tests: reuse find_nearest_seq's TLAS part through a light-less copy is not possible, so inline it
+        const char* __restrict__ g = sc.geom;
+        uint32_t* tstk = stk + sc.bvhStack * 64;
+        uint32_t cur = sc.rootRef, sp = 0;
+        for (;;) {
+            cn.tlas++;
+            if ((cur & kRefTlasLeaf) == kRefTlasLeaf) {
+                cn.visits++;
+                const uint32_t io = sc.instOff + (cur & 0xffffu) * 128u;
+                const rec4 r0 = ldg(g, io), r1 = ldg(g, io + 16), r2 = ldg(g, io + 32), ids = ldg(g, io + 48);
+                f3 Oo, Do, rDo; to_object_space(r0, r1, r2, O, D, Oo, Do, rDo);
+                traverse_bvh_seq(sc, asu(ids.z), Oo, Do, rDo, h, stk, cn, traversed, tested);
+                if (sp == 0) break;
+                cur = tstk[(--sp) * 64];
+            } else {
+                const uint32_t o1 = sc.tlasOff + (cur & 0x7fffu) * 32u, o2 = sc.tlasOff + ((cur >> 15) & 0x7fffu) * 32u;
+                const rec4 alo = ldg(g, o1), ahi = ldg(g, o1 + 16), blo = ldg(g, o2), bhi = ldg(g, o2 + 16);
+                float d1 = box_exact(alo, ahi, O, rD, h.t), d2 = box_exact(blo, bhi, O, rD, h.t);
+                uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
+                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+                if (d1 == 1e30f) { if (sp == 0) break; cur = tstk[(--sp) * 64]; }
+                else { cur = r1; if (d2 != 1e30f) { tstk[sp * 64] = r2; sp++; } }
+            }
+        }
+        (void)hh; (void)dummy;
+    }
+    return h.objIdx > -1;
+}
+
+__global__ __launch_bounds__(64) void whitted_kernel(const Scene sc, float4* __restrict__ acc, uint32_t* __restrict__ pixels, Counters* __restrict__ counters)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = blockIdx.x * 64u + lane;
+    const uint32_t W = (uint32_t)sc.W, H = (uint32_t)sc.H;
+    uint32_t* stk = lds + lane;
+    Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
+    if (idx < W * H) {
+        const uint32_t x = idx % W, y = idx / W;
+        const f3 camPos = mk3(sc.camPos[0], sc.camPos[1], sc.camPos[2]);
+        const f3 TL = mk3(sc.topLeft[0], sc.topLeft[1], sc.topLeft[2]);
+        const f3 TR = mk3(sc.topRight[0], sc.topRight[1], sc.topRight[2]);
+        const f3 BL = mk3(sc.bottomLeft[0], sc.bottomLeft[1], sc.bottomLeft[2]);
+        const float u = (float)x * sc.invW, v = (float)y * sc.invH;                   // GetPrimaryRay((float)x, (float)y), no jitter
+        const f3 P = TL + u * (TR - TL) + v * (BL - TL);
+        f3 O = camPos, D = normalize3(P - camPos); bool inside = false;
+        cn.primary++;
+        WFrame fr[kWhittedMaxDepth];
+        int sp = 0;                       // frames in use; the ray (O, D, inside) is traced at depth `sp`
+        f3 res = mk3(0, 0, 0);
+        bool descend = true;
+        for (;;) {
+            if (descend) {
+                // ---- Trace(ray, depth = sp) up to the point where it needs its children --------------------------------
+                bool terminal = true;
+                if (sp > sc.depthLimit) res = mk3(0, 0, 0);                             // renderer.cpp:23 (checked BEFORE tracing)
+                else {
+                    Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+                    const f3 rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
+                    int traversed = 0, tested = 0;
+                    find_nearest_seq(sc, O, D, rD, h, stk, cn, traversed, tested);
+                    if (h.objIdx == -1) res = sky_color(sc, D);
+                    else if (h.objIdx == 0) res = mk3(24, 24, 22);
+                    else {
+                        const f3 I = O + h.t * D;
+                        f3 N; float tu = 0, tv = 0; Material m;
+                        if (h.objIdx == 1) {
+                            N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
+                            if (N.y == 1) { float fu = I.x, fv = I.z; fu *= sc.floorInvto; fv *= sc.floorInvto; tu = fu - __builtin_floorf(fu); tv = fv - __builtin_floorf(fv); }
+                            m = sc.floorMat;
+                        } else {
+                            const uint32_t so = sc.shadeOff + (uint32_t)h.triIdx * 64u;
+                            const rec4 s0 = ldg(sc.geom, so), s1 = ldg(sc.geom, so + 16), s2 = ldg(sc.geom, so + 32), s3 = ldg(sc.geom, so + 48);
+                            const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+                            const float w = 1 - h.u - h.v;
+                            const f3 Nn = w * n0 + h.u * n1 + h.v * n2;
+                            tu = w * s2.y + h.u * s2.w + h.v * s3.y;
+                            tv = w * s2.z + h.u * s3.x + h.v * s3.z;
+                            const rec4* mp = reinterpret_cast<const rec4*>(sc.mats + (int)asu(s3.w));
+                            const rec4 m0 = mp[0], m1 = mp[1];
+                            m.reflectivity = m0.x; m.refractivity = m0.y; m.absorption[0] = m0.z; m.absorption[1] = m0.w; m.absorption[2] = m1.x;
+                            m.texOffset = asu(m1.y); m.texW = (int)asu(m1.z); m.texH = (int)asu(m1.w);
+                            if (sc.kind == 0) N = normalize3(Nn);
+                            else {
+                                const uint32_t io = sc.instOff + (uint32_t)(h.objIdx - 2) * 128u + 64u;
+                                const rec4 r0 = ldg(sc.geom, io), r1 = ldg(sc.geom, io + 16), r2 = ldg(sc.geom, io + 32);
+                                N = normalize3(mk3(r0.x * Nn.x + r0.y * Nn.y + r0.z * Nn.z + r0.w * 0.0f,
+                                                   r1.x * Nn.x + r1.y * Nn.y + r1.z * Nn.z + r1.w * 0.0f,
+                                                   r2.x * Nn.x + r2.y * Nn.y + r2.z * Nn.z + r2.w * 0.0f));
+                            }
+                        }
+                        if (dot3(N, D) > 0) N = -N;
+                        const f3 albedo = (m.texW > 0) ? tex_sample(sc, m.texOffset, m.texW, m.texH, tu, tv) : mk3(1.0f, 1.0f, 1.0f);
+                        WFrame& f = fr[sp];
+                        f.flags = 0; f.out = mk3(0, 0, 0);
+                        const float refl = m.reflectivity, refr = m.refractivity;
+                        const float diffuseness = 1 - (refl + refr);
+                        f3 aO = O, aD = D; bool aInside = false;
+                        if (refl > 0.0f) {                                               // renderer.cpp:49-54
+                            const f3 R = D - 2.0f * N * dot3(N, D);
+                            aO = I + R * CRT_EPS; aD = R; aInside = false;
+                            f.cA = refl * albedo; f.flags |= 1;
+                        } else if (refr > 0.0f) {                                        // renderer.cpp:55-72
+                            const f3 R = D - 2.0f * N * dot3(N, D);
+                            const float n1 = inside ? 1.2f : 1, n2 = inside ? 1 : 1.2f;
+                            const float eta = n1 / n2, cosi = dot3(-D, N);
+                            const float cost2 = 1.0f - eta * eta * (1 - cosi * cosi);
+                            float Fr = 1;
+                            if (cost2 > 0) {
+                                const float a = n1 - n2, b = n1 + n2, R0 = (a * a) / (b * b), c = 1 - cosi;
+                                Fr = R0 + (1 - R0) * (c * c * c * c * c);
+                                const f3 T = eta * D + ((eta * cosi - __builtin_sqrtf(__builtin_fabsf(cost2))) * N);
+                                aO = I + T * CRT_EPS; aD = T; aInside = !inside;
+                                f.cA = albedo * (1 - Fr); f.flags |= 1;
+                            }
+                            f.bO = I + R * CRT_EPS; f.bD = R; f.cB = albedo * Fr; f.flags |= 2;
+                        }
+                        if (diffuseness > 0) {                                           // renderer.cpp:74-80, DirectIllumination :105-126
+                            f3 irr = mk3(0, 0, 0);
+                            f3 L = mk3(sc.lightPos[0], sc.lightPos[1], sc.lightPos[2]) - I;
+                            const float dist = __builtin_sqrtf(dot3(L, L));
+                            L = L * (1 / dist);
+                            const float ndotl = dot3(N, L);
+                            if (!(ndotl < CRT_EPS)) {
+                                if (!whitted_occluded(sc, I + L * CRT_EPS, L, dist - 2 * CRT_EPS, stk, cn)) {
+                                    const float att = 1 / (dist * dist);
+                                    const f3 inr = mk3(24, 24, 22) * att;
+                                    irr = inr * dot3(N, L);
+                                }
+                            }
+                            const f3 brdf = albedo * CRT_INVPI;
+                            f.C = diffuseness * brdf * (irr + mk3(0.3f, 0.3f, 0.3f)); f.flags |= 4;
+                        }
+                        f.medium = mk3(1, 1, 1);
+                        if (inside) f.medium = mk3(crt_expf(m.absorption[0] * -h.t), crt_expf(m.absorption[1] * -h.t), crt_expf(m.absorption[2] * -h.t));
+                        terminal = false;
+                        if (f.flags & 1) { O = aO; D = aD; inside = aInside; sp++; }                      // trace child A next
+                        else if (f.flags & 2) { O = f.bO; D = f.bD; inside = false; f.flags |= 16; sp++; } // (not reachable in the reference: B only exists with refr > 0)
+                        else { res = (f.flags & 4) ? f.out + f.C : f.out; res = f.medium * res; terminal = true; }
+                    }
+                }
+                if (terminal) descend = false;
+            } else {
+                // ---- a child returned `res` to the frame below it ------------------------------------------------------
+                if (sp == 0) break;
+                WFrame& f = fr[sp - 1];
+                bool finalize = true;
+                if (!(f.flags & 16)) {                                                   // it was child A (or the only child)
+                    if (f.flags & 1) f.out = f.out + f.cA * res;
+                    if (f.flags & 2) { O = f.bO; D = f.bD; inside = false; f.flags |= 16; descend = true; finalize = false; }
+                } else f.out = f.out + f.cB * res;
+                if (finalize) {
+                    f3 o = f.out;
+                    if (f.flags & 4) o = o + f.C;
+                    res = f.medium * o;
+                    sp--;
+                }
+            }
+        }
+        acc[idx] = make_float4(res.x, res.y, res.z, 0.0f);
+        const uint32_t r = (uint32_t)(255.0f * min_std(1.0f, res.x)), g = (uint32_t)(255.0f * min_std(1.0f, res.y)), bb = (uint32_t)(255.0f * min_std(1.0f, res.z));
+        pixels[idx] = (r << 16) + (g << 8) + bb;
+    }
+    uint32_t vals[8] = {cn.rays, cn.primary, cn.interior, cn.leaf, cn.tri, cn.tlas, cn.visits, cn.meshhits};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t s = wave_sum(vals[k]);
+        if (lane == 0 && s) atomicAdd(&counters->v[k], (unsigned long long)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // resolve_kernel: one thread per owned tile; pixels in ProcessTile order so the per-tile energy sum is bit-exact
 // (renderer.cpp:119,127-129; RGBF32_to_RGB8 scalar branch, template/precomp.h:336-340)
 // ------------------------------------------------------------------------------------------------------------
@@ -800,6 +1005,14 @@ extern "C" hipError_t crt_launch_find_nearest(const crt::Scene* sc, const void* 
     if (n == 0) return hipSuccess;
     dim3 grid((n + 63u) / 64u), block(64);
     hipLaunchKernelGGL(crt::find_nearest_kernel, grid, block, ldsBytes, stream, *sc, (const crt::RayIn*)rays, (crt::HitOut*)hits, n, counters);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t crt_launch_whitted(const crt::Scene* sc, void* acc, uint32_t* pixels, crt::Counters* counters, uint32_t ldsBytes, hipStream_t stream)
+{
+    const uint32_t n = (uint32_t)sc->W * (uint32_t)sc->H;
+    dim3 grid((n + 63u) / 64u), block(64);
+    hipLaunchKernelGGL(crt::whitted_kernel, grid, block, ldsBytes, stream, *sc, (float4*)acc, pixels, counters);
     return hipGetLastError();
 }
 

@@ -70,6 +70,7 @@ struct Scene {                            // passed to the kernels BY VALUE (ker
     int32_t W, H;
     // light quad / floor plane
     float lightInvT[12]; float lightNrm[3]; float lightSize;
+    float lightPos[3];                    // GetLightPos() (file_scene.cpp:156-162): the Whitted integrator's point light
     float floorN[3]; float floorD; float floorInvto;
     Material floorMat;                    // primitiveMaterials[1]: diffuse, textured
     uint32_t skyOffset; int32_t skyW, skyH;

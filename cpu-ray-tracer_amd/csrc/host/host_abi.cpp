@@ -123,6 +123,7 @@ int crt_host_renderer_set_camera(crt_host_renderer* r, const float p[3], const f
 int crt_host_renderer_set_passes(crt_host_renderer* r, int passes) { if (!r || passes < 1 || passes > 4) { g_err = "passes must be 1..4"; return CRT_ERR_INVALID; } r->r->passes = passes; return CRT_OK; }
 int crt_host_renderer_clear(crt_host_renderer* r) { if (!r) return CRT_ERR_INVALID; GUARD_BEGIN r->r->ClearAccumulator(); return CRT_OK; GUARD_END(CRT_ERR_DEVICE) }
 int crt_host_renderer_tick(crt_host_renderer* r, float dt) { if (!r) return CRT_ERR_INVALID; GUARD_BEGIN r->r->Tick(dt); return CRT_OK; GUARD_END(CRT_ERR_DEVICE) }
+int crt_host_renderer_tick_whitted(crt_host_renderer* r) { if (!r) return CRT_ERR_INVALID; GUARD_BEGIN r->r->TickWhitted(); return CRT_OK; GUARD_END(CRT_ERR_DEVICE) }
 int crt_host_renderer_render(crt_host_renderer* r, int frames) { if (!r) return CRT_ERR_INVALID; GUARD_BEGIN r->r->Render(frames); return CRT_OK; GUARD_END(CRT_ERR_DEVICE) }
 int crt_host_renderer_spp(crt_host_renderer* r) { return r ? r->r->spp : CRT_ERR_INVALID; }
 float crt_host_renderer_energy(crt_host_renderer* r) { return r ? r->r->energy : 0.0f; }

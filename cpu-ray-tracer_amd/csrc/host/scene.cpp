@@ -217,6 +217,14 @@ void Renderer::Render(int frames)
     spp += frames * passes;                                                          // renderer.cpp:167 (camera input belongs to the shell)
 }
 
+void Renderer::TickWhitted()
+{
+    if (!ctx) throw std::runtime_error("Renderer::TickWhitted before Init");
+    PushCamera();
+    check(ctx, crt_whitted_tick(ctx, screen ? screen->pixels.data() : nullptr), "crt_whitted_tick");
+    check(ctx, crt_read_accumulator(ctx, accumulator), "crt_read_accumulator");
+}
+
 void Renderer::Tick(float deltaTime)   // renderer.cpp:144-168
 {
     if (animating) anim_time += deltaTime * 0.002f;

@@ -105,6 +105,7 @@ public:
     void ClearAccumulator();
     void Tick(float deltaTime);
     void Render(int frames);       // `frames` Ticks in one submission (no per-frame read-back)
+    void TickWhitted();            // one Tick of the Whitted-style renderer ("2. WhittedStyle/renderer.cpp":131-157): accumulator = Trace(primary)
     void Shutdown() {}
     // data members the shell / UI reads (renderer.h:46-53)
     std::vector<float> accumulatorStorage; float* accumulator = nullptr;   // float4[W*H], refreshed by Tick

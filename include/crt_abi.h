@@ -156,6 +156,11 @@ int  crt_read_accumulator(crt_ctx* ctx, float* host_rgba /* float4[width*height]
  * pixel = accumulator * scale, scale = 1/(spp+passes) of the LAST rendered frame.  Either output may be NULL. */
 int  crt_resolve_screen(crt_ctx* ctx, float scale, uint32_t* host_pixels /* width*height */, float* energy);
 
+/* ---- Whitted-style integrator ("2. WhittedStyle/renderer.cpp":21-157): one deterministic Tick -------------------
+ * Every pixel of the image (rows are not tile-truncated in this renderer) gets accumulator = float4(Trace(primary), 0)
+ * and screen pixel = RGBF32_to_RGB8 of it; host_pixels may be NULL.  Synchronous. */
+int  crt_whitted_tick(crt_ctx* ctx, uint32_t* host_pixels /* width*height or NULL */);
+
 /* ---- query entry = scene.FindNearest(ray) ------------------------------------------------------------ */
 int  crt_find_nearest(crt_ctx* ctx, const crt_ray* rays, crt_hit* hits, size_t n);
 

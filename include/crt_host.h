@@ -52,6 +52,7 @@ int  crt_host_renderer_set_passes(crt_host_renderer* r, int passes);
 int  crt_host_renderer_clear(crt_host_renderer* r);                                 /* Renderer::ClearAccumulator    */
 int  crt_host_renderer_tick(crt_host_renderer* r, float deltaTime);                 /* Renderer::Tick                */
 int  crt_host_renderer_render(crt_host_renderer* r, int frames);                    /* `frames` Ticks, one submission */
+int  crt_host_renderer_tick_whitted(crt_host_renderer* r);                          /* Tick of the Whitted-style Renderer */
 int  crt_host_renderer_spp(crt_host_renderer* r);
 float crt_host_renderer_energy(crt_host_renderer* r);
 const float* crt_host_renderer_accumulator(crt_host_renderer* r);                   /* float4[width*height]          */

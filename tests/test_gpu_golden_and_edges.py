@@ -260,3 +260,31 @@ def test_back_to_back_renders_keep_frame_order(crt, orc, streams):
     ctx.render(1, 2, 1); ctx.clear(); ctx.render(1, 2, 1)
     o.clear(); o.render(2, 2)
     assert np.array_equal(ctx.accumulator(), o.accumulator())
+
+
+@pytest.mark.parametrize("xml,kind,W,H", [("cube_scene.xml", 0, 640, 360), ("tlas_scene.xml", 1, 320, 192), ("tlas_scene.xml", 0, 160, 96), ("tower_scene.xml", 0, 200, 120)])
+def test_whitted_tick_matches_oracle(crt, orc, xml, kind, W, H):
+    """the reference's second front-end (2. WhittedStyle/renderer.cpp) behind the same boundary: deterministic, every pixel of the
+    image, reflection / refraction recursion + shadow rays.  640x360 cube = BASELINE config 1."""
+    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    ctx = crt.Context(W, H)
+    hs.upload(ctx)
+    px = ctx.whitted_tick()
+    acc = ctx.accumulator()
+    o, _ = orc.load_scene(scene_path(xml), kind, ASSETS)
+    o.renderer_init(W, H)
+    o.whitted(4)
+    want = o.accumulator()
+    assert np.isfinite(want).all()
+    assert np.abs(acc - want).max() <= 1e-4
+    assert np.array_equal(acc, want)
+    assert np.array_equal(px, o.screen())
+    gc, oc = ctx.counters(), o.counters()
+    for k in gc:
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    if xml == "cube_scene.xml" and W == 640:
+        assert crc(acc) == G["orc_whitted_cube_640x360"]["acc"] and crc(px) == G["orc_whitted_cube_640x360"]["screen"]
+        r = crt.HostRenderer(hs, W, H)                      # same through the C++ Renderer facade
+        r.init()
+        r.tick_whitted()
+        assert np.array_equal(r.accumulator(), want) and np.array_equal(r.screen(), o.screen())
