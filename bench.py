@@ -9,10 +9,11 @@ textures) already resident in HBM.  Rays = FindNearest calls (primary + secondar
     python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Steps are the consecutive 64-frame windows of ONE progressive render (spp 1..64, 65..128, ...): they are independent
-((tile, frame) streams, renderer.cpp:120) except for the accumulation order, so they are submitted back to back, their
-kernels overlap on the context's HIP streams, and the ordered accumulate kernels follow behind events.
-Multi-GPU (weak scaling): windows are dealt round-robin over the ranks, every rank renders the full image for its
-windows, and ONE RCCL all-reduce of the float4 accumulators over xGMI closes the job (image = 64*K*N spp).
+((tile, frame) streams, renderer.cpp:120) except for the accumulation order, so the K steps are submitted as one
+crt_render of 64*K frames: the back end covers up to 64 windows with ONE render_tiles_kernel grid (a wavefront per
+(tile, window), expensive tiles first) and adds the samples to the accumulator in frame order behind it.
+Multi-GPU (weak scaling): every rank renders its own K consecutive windows of the full image (rank r: windows r*K ..),
+and ONE RCCL all-reduce of the float4 accumulators over xGMI closes the job (image = 64*K*N spp).
 `value` = rays of all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line with the contract fields + "roofline" (dominant kernel = render_tiles_kernel, HIP events
@@ -127,32 +128,31 @@ def main():
     scene.upload(ctx)                                             # one-time flatten + copy to HBM
     acc = torch.zeros(H, W, 4, dtype=torch.float32, device="cuda:%d" % device)
     ctx.bind_accumulator(acc.data_ptr())
-    def window(i):
-        """spp counter of the first frame of this rank's i-th step: steps are consecutive 64-frame windows of ONE progressive
-        render, dealt round-robin over the ranks (window i*world + rank)"""
-        return crt.spp_window(i * world + rank, SPP)
+    def window(i, n_steps):
+        """spp counter of the first frame of this rank's i-th step of an n_steps job: steps are consecutive 64-frame windows of ONE
+        progressive render; rank r owns the windows r*n_steps .. r*n_steps + n_steps - 1"""
+        return crt.spp_window(rank * n_steps + i, SPP)
 
     # one counted pass over the same windows with a statistics context (untimed) -> algorithmic bytes per launch
     sctx = crt.Context(W, H, device=device, collect_stats=True)
     scene.upload(sctx)
-    for i in range(args.steps):
-        sctx.render(window(i), SPP, 1)
+    sctx.render(window(0, args.steps), SPP * args.steps, 1)      # (a statistics context renders window by window)
     sctx.sync()
     counts = {k: v / args.steps for k, v in sctx.counters().items()}
     sctx.close()
 
-    def run(n_steps, first=0):
-        """n_steps steps submitted back to back: every step = 64 frames = one render_tiles_kernel launch (+ its ordered accumulate);
-        launches rotate over the context's HIP streams and overlap; one sync (and, for N > 1, ONE RCCL all-reduce of the float4
-        accumulators over xGMI) closes the job."""
+    def run(n_steps):
+        """n_steps steps = 64*n_steps frames submitted as one job: the back end renders up to 64 windows per render_tiles_kernel
+        launch and accumulates them in frame order; one sync (and, for N > 1, ONE RCCL all-reduce of the float4 accumulators
+        over xGMI) closes the job."""
         ctx.clear()
-        for i in range(first, first + n_steps):
-            ctx.render(window(i), SPP, 1)
+        ctx.render(window(0, n_steps), SPP * n_steps, 1)
         ctx.sync()
         if dist is not None:
             crt.allreduce_accumulator(acc, dist)
             torch.cuda.synchronize()
 
+    ctx.reserve(SPP * max(args.steps, args.warmup), 1)             # sample-slab pool for the whole job, allocated outside the timed region
     run(args.warmup)
     ctx.timing()
     ctx.reset_counters()
@@ -172,7 +172,7 @@ def main():
     lat = []
     for i in range(3):
         t1 = time.perf_counter()
-        ctx.render(window(i), SPP, 1)
+        ctx.render(window(i, args.steps), SPP, 1)
         ctx.sync()
         lat.append((time.perf_counter() - t1) * 1e3)
     ctx.timing()
@@ -192,7 +192,7 @@ def main():
     ms_step = elapsed / args.steps * 1e3
     avg_launch_ms = kernel_ms / max(launches, 1)
     launches_per_step = launches / args.steps
-    alg_bytes_launch = algorithmic_bytes(counts) / max(launches_per_step, 1)
+    alg_bytes_launch = algorithmic_bytes(counts) / launches_per_step if launches_per_step > 0 else 0.0
     achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     traffic = None
     pmc_path = os.path.join(REPO, "profiles", "hbm_traffic.json")
@@ -211,10 +211,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %s BVH-SAH path tracer, %dx%d, %d spp/step (passes=1, depthLimit=5); 1 step = %d frames = the next spp window of a "
-                               "progressive render (one render_tiles_kernel launch + ordered accumulate); steps are submitted back to back and overlap on "
-                               "%d HIP streams, one sync at the end%s"
-                               % (args.scene, "TLASFileScene" if args.kind else "FileScene", W, H, SPP, SPP, args.streams,
-                                  "" if world == 1 else "; windows dealt round-robin over %d ranks, ONE RCCL all-reduce of the float4 accumulator closes the job" % world),
+                               "progressive render; the %d steps are one crt_render job (%d render_tiles_kernel launch(es), a wavefront per (tile, window), "
+                               "+ ordered accumulate), one sync at the end%s"
+                               % (args.scene, "TLASFileScene" if args.kind else "FileScene", W, H, SPP, SPP, args.steps, launches,
+                                  "" if world == 1 else "; every one of the %d ranks renders its own %d windows, ONE RCCL all-reduce of the float4 accumulator closes the job" % (world, args.steps)),
                    "latency_ms_single_step": round(sorted(lat)[1], 3),
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
                    "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},
@@ -222,11 +222,10 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel": "render_tiles_kernel", "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-                     "concurrent_launches": args.streams,
                      "job_achieved": round(rays / elapsed * (alg_bytes_launch / max(counts["rays"], 1)) / 1e9, 2),
                      "accumulate_kernel_ms_per_step": round(acc_ms / args.steps, 4),
                      "counters_per_step": {k: round(v) for k, v in counts.items()},
-                     "note": "achieved = algorithmic bytes of ONE launch / its mean duration (HIP events on its stream); concurrent_launches of them overlap, job_achieved = algorithmic GB/s of the whole job"},
+                     "note": "achieved = algorithmic bytes of one launch / its mean duration (HIP events on its stream); job_achieved = algorithmic GB/s over the whole timed region (incl. the ordered accumulate)"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(xml, args.kind, W, H)

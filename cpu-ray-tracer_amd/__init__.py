@@ -52,7 +52,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("objIdx", "<i4"
 
 # every symbol include/crt_abi.h and include/crt_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = ["crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
-               "crt_render", "crt_whitted_tick", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
+               "crt_render", "crt_reserve", "crt_whitted_tick", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
                "crt_reset_counters", "crt_get_timing", "crt_get_tile_clocks", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
 HOST_SYMBOLS = ["crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
                 "crt_host_scene_triangle_count", "crt_host_scene_bvh_count", "crt_host_scene_bvh_info", "crt_host_scene_bvh_copy",
@@ -162,6 +162,9 @@ class Context:
 
     def render(self, spp_first, frames, passes=1):
         self._ck(self.L.crt_render(self.h, C.c_uint32(spp_first), C.c_uint32(frames), C.c_uint32(passes)))
+
+    def reserve(self, frames, passes=1):
+        self._ck(self.L.crt_reserve(self.h, C.c_uint32(frames), C.c_uint32(passes)))
 
     def whitted_tick(self):
         px = np.empty((self.H, self.W), np.uint32)

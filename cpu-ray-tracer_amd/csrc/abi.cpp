@@ -12,11 +12,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
 extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
-extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_whitted(const crt::Scene*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_resolve(const void*, uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float, hipStream_t);
@@ -42,10 +43,15 @@ struct crt_ctx {
     uint32_t tileFirst = 0, tileStride = 1, tileCount = 0;
     // device memory
     void* dAccOwned = nullptr; void* dAcc = nullptr;
-    // render lanes: each has its own HIP stream + sample slab, so consecutive 64-frame launches (which are independent:
-    // different spp windows) overlap on the GPU; the ordered accumulate kernels run on the main stream behind events
-    struct Lane { hipStream_t s = nullptr; void* slab = nullptr; size_t bytes = 0; hipEvent_t slabFree = nullptr; bool pendingFree = false; };
-    std::vector<Lane> lanes; uint64_t launchSeq = 0;
+    // Render launches (independent: different spp windows) rotate over `streams` so that consecutive crt_render calls overlap on
+    // the GPU; the ordered accumulate kernels run on the main stream behind events.  Their sample slabs are regions of ONE pool
+    // handed out as a ring: launch order = accumulate order = release order, so the oldest region is always the next to free.
+    std::vector<hipStream_t> streams; uint64_t launchSeq = 0;
+    struct Region { size_t off, bytes; hipEvent_t freed; };      // freed: recorded on the main stream behind the region's accumulate
+    std::deque<Region> inflight;
+    char* pool = nullptr; size_t poolBytes = 0, poolHead = 0; bool poolCapped = false;   // capped: already as large as the HBM budget allows
+    hipEvent_t mustWait = nullptr;                                // `freed` of the newest region whose space was handed out again
+    std::vector<hipEvent_t> freeEvents;
     std::vector<hipEvent_t> doneEvents;
     crt::Scene hScene{};
     crt::Counters* dCounters = nullptr;
@@ -149,7 +155,9 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     c->cfg = *cfg;
     if (c->cfg.depthLimit < 0) c->cfg.depthLimit = 5;
     if (c->cfg.depthLimit > 5) { g_createError = "crt_create: depthLimit > 5 unsupported (throughput stack holds 5 factors; reference default is 5)"; delete c; return CRT_ERR_UNSUPPORTED; }
-    if (c->cfg.maxFramesPerLaunch <= 0 || c->cfg.maxFramesPerLaunch > 64) c->cfg.maxFramesPerLaunch = 64;
+    if (c->cfg.maxFramesPerLaunch <= 0) c->cfg.maxFramesPerLaunch = 4096;                     // 64 windows of 64 frames
+    if (c->cfg.maxFramesPerLaunch > 64) c->cfg.maxFramesPerLaunch = c->cfg.maxFramesPerLaunch / 64 * 64;   // whole windows (< 64: one partial window per launch)
+    if (c->cfg.collectStats) c->cfg.maxFramesPerLaunch = 64;                                  // per-tile clocks describe ONE window
     if (c->cfg.renderStreams < 0) c->cfg.renderStreams = 0;
     c->tilesX = cfg->width / 16; c->tilesY = cfg->height / 16;      // truncating, as renderer.cpp:151
     const int tiles = c->tilesX * c->tilesY;
@@ -177,8 +185,8 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     if ((e = hipMalloc((void**)&c->dCounters, sizeof(crt::Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemsetAsync(c->dCounters, 0, sizeof(crt::Counters), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
     if (c->cfg.collectStats && count > 0) {
-        if ((e = hipMalloc((void**)&c->dTileClocks, (size_t)count * 96)) != hipSuccess) return bail(e, "hipMalloc(tileClocks)");
-        if ((e = hipMemsetAsync(c->dTileClocks, 0, (size_t)count * 96, c->stream)) != hipSuccess) return bail(e, "hipMemset(tileClocks)");
+        if ((e = hipMalloc((void**)&c->dTileClocks, (size_t)count * 144)) != hipSuccess) return bail(e, "hipMalloc(tileClocks)");
+        if ((e = hipMemsetAsync(c->dTileClocks, 0, (size_t)count * 144, c->stream)) != hipSuccess) return bail(e, "hipMemset(tileClocks)");
     }
     // Camera() defaults, template/camera.h:14-22
     memset(&c->hScene, 0, sizeof(c->hScene));
@@ -203,7 +211,11 @@ void crt_destroy(crt_ctx* c)
     c->freeScene();
     for (auto& ev : c->evPool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (c->dAccOwned) (void)hipFree(c->dAccOwned);
-    for (auto& l : c->lanes) { if (l.s) (void)hipStreamSynchronize(l.s); if (l.slab) (void)hipFree(l.slab); if (l.slabFree) (void)hipEventDestroy(l.slabFree); if (l.s) (void)hipStreamDestroy(l.s); }
+    for (auto st : c->streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto& r : c->inflight) (void)hipEventDestroy(r.freed);
+    for (auto e : c->freeEvents) (void)hipEventDestroy(e);
+    if (c->mustWait) (void)hipEventDestroy(c->mustWait);
+    if (c->pool) (void)hipFree(c->pool);
     for (auto e : c->doneEvents) (void)hipEventDestroy(e);
     if (c->dPixels) (void)hipFree(c->dPixels);
     if (c->dTileSums) (void)hipFree(c->dTileSums);
@@ -390,6 +402,11 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         s.lightPos[0] = (c1[0] + c2[0]) * 0.5f - 0.0f; s.lightPos[1] = (c1[1] + c2[1]) * 0.5f - 0.01f; s.lightPos[2] = (c1[2] + c2[2]) * 0.5f - 0.0f;
     }
     memcpy(s.floorN, sd->floorN, 12); s.floorD = sd->floorD; s.floorInvto = sd->floorInvto;
+    {   // what FileScene / TLASFileScene always build: a translated, unrotated quad and the y-up floor plane
+        const float* m = sd->lightInvT;
+        s.lightAxis = (m[0] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f && m[5] == 1.0f && m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f && m[10] == 1.0f) ? 1u : 0u;
+        s.floorAxisY = (sd->floorN[0] == 0.0f && sd->floorN[1] == 1.0f && sd->floorN[2] == 0.0f) ? 1u : 0u;
+    }
     s.floorMat = mats[1];
     s.skyOffset = texOff[sd->skyTexture]; s.skyW = sd->textures[sd->skyTexture].width; s.skyH = sd->textures[sd->skyTexture].height;
     s.texels = dTexels;
@@ -401,6 +418,17 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     if ((r = upload(c, mats, &s.mats))) return r;
     s.rootRef = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot : rootRef0;
     s.bvhStack = maxHeight + 2;
+    // the root's two children also travel in the kernel arguments: the render kernel takes every ray's first traversal step from scalar registers
+    s.rootIsPair = 0; memset(s.rootPair, 0, sizeof(s.rootPair));
+    if (sd->kind == CRT_SCENE_TLAS) {
+        if ((tlasRoot & 0xC0000000u) == crt::kRefTlasInterior) {
+            memcpy(s.rootPair, &tlas[tlasRoot & 0x7fffu], 32); memcpy(s.rootPair + 8, &tlas[(tlasRoot >> 15) & 0x7fffu], 32);
+            s.rootIsPair = 1;
+        }
+    } else if (rootRef0 & crt::kRefInterior) {
+        memcpy(s.rootPair, geom.data() + ((size_t)(rootRef0 & crt::kRefOffsetMask) << 4), 64);
+        s.rootIsPair = 1;
+    }
     s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 3 : 0);   // + TLAS pushes + the return marker + slack
     c->ldsBytes = s.stackDepth * 64u * 4u;
     if (const char* e = getenv("CRT_DEBUG_EXTRA_LDS")) c->ldsBytes += (uint32_t)atoi(e);   // occupancy experiments only
@@ -464,7 +492,7 @@ static int update_tile_order(crt_ctx* c)
     first.insert(first.end(), rest.begin(), rest.end());
     if (!c->dTileOrder) HIPCK(c, hipMalloc((void**)&c->dTileOrder, (size_t)c->tileCount * 4));
     HIPCK(c, hipStreamSynchronize(c->stream));              // launches in flight still read the previous order
-    for (auto& l : c->lanes) HIPCK(c, hipStreamSynchronize(l.s));
+    for (auto st : c->streams) HIPCK(c, hipStreamSynchronize(st));
     HIPCK(c, hipMemcpy(c->dTileOrder, first.data(), first.size() * 4, hipMemcpyHostToDevice));
     c->orderDirty = false;
     return 0;
@@ -480,6 +508,82 @@ static int take_event(crt_ctx* c, std::vector<EventPair>& list, EventPair* out)
     return 0;
 }
 
+// Sizes the sample-slab pool for a crt_render of `frames` frames and returns the frames per launch to use (*maxFOut).
+// One launch renders up to cfg.maxFramesPerLaunch frames = that many / 64 windows; its samples need windowBytes per window.  The pool
+// grows to the high-water mark only (hipMalloc synchronises the device and takes seconds for tens of GB): room for the largest
+// launch — for two of them when a call needs several launches — and for at least eight windows (consecutive single-window calls
+// overlap on the streams), never more than half of the free HBM.
+static int ensure_pool(crt_ctx* c, uint32_t frames, uint32_t passes, uint32_t* maxFOut)
+{
+    const size_t windowBytes = (size_t)c->tileCount * 256u * 64u * passes * 16u;
+    uint32_t maxF = (uint32_t)c->cfg.maxFramesPerLaunch;
+    uint32_t maxW = maxF >= 64u ? maxF / 64u : 1u;
+    const uint32_t wantW = (frames + 63u) / 64u;                                          // (an upper bound when maxF < 64)
+    const uint32_t callW = wantW < maxW ? wantW : maxW;                                   // windows of this call's largest launch
+    size_t want = (size_t)callW * windowBytes * (wantW > callW ? 2u : 1u);
+    if (want < 8 * windowBytes) want = 8 * windowBytes;
+    if (want > c->poolBytes && !(c->poolCapped && windowBytes <= c->poolBytes)) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        for (auto st : c->streams) HIPCK(c, hipStreamSynchronize(st));
+        for (auto& r : c->inflight) c->freeEvents.push_back(r.freed);
+        c->inflight.clear(); c->poolHead = 0;
+        if (c->pool) { HIPCK(c, hipFree(c->pool)); c->pool = nullptr; c->poolBytes = 0; }
+        size_t freeB = 0, totalB = 0;
+        HIPCK(c, hipMemGetInfo(&freeB, &totalB));
+        const size_t budget = freeB / 2;
+        if (budget < windowBytes) return c->fail(CRT_ERR_DEVICE, "not enough free HBM for one 64-frame sample slab (%zu bytes needed, %zu free)", windowBytes, freeB);
+        c->poolCapped = want > budget;
+        if (want > budget) want = budget;
+        want = want / windowBytes * windowBytes;
+        HIPCK(c, hipMalloc((void**)&c->pool, want));
+        c->poolBytes = want;
+    }
+    {   // launches must fit the pool; when the call needs several launches leave room for two in flight
+        uint32_t fitW = (uint32_t)(c->poolBytes / windowBytes);
+        if (wantW > fitW && fitW >= 2) fitW /= 2;
+        if (maxW > fitW) maxW = fitW;
+    }
+    if (maxF >= 64u) maxF = maxW * 64u;
+    *maxFOut = maxF;
+    return 0;
+}
+
+int crt_reserve(crt_ctx* c, uint32_t frames, uint32_t passes)
+{
+    if (!c) return CRT_ERR_INVALID;
+    if (passes < 1 || passes > 4) return c->fail(CRT_ERR_INVALID, "passes must be 1..4");
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (c->tileCount == 0 || frames == 0) return CRT_OK;
+    uint32_t maxF = 0;
+    return ensure_pool(c, frames, passes, &maxF);
+}
+
+// a region of `need` bytes of the slab pool for a launch on stream `st`; regions still in use are waited for on the GPU (never on the host)
+static int take_region(crt_ctx* c, size_t need, hipStream_t st, size_t* offOut)
+{
+    for (;;) {
+        bool ok = false; size_t off = 0;
+        if (c->inflight.empty()) { off = 0; ok = need <= c->poolBytes; }
+        else {
+            const size_t tail = c->inflight.front().off;                     // oldest region still held
+            if (c->poolHead > tail) {                                        // free: [head, end) and [0, tail)
+                if (c->poolBytes - c->poolHead >= need) { off = c->poolHead; ok = true; }
+                else if (tail >= need) { off = 0; ok = true; }
+            } else if (c->poolHead < tail && tail - c->poolHead >= need) { off = c->poolHead; ok = true; }
+        }
+        if (ok) {
+            // every launch is ordered behind the release of ALL space handed out again so far (releases are ordered on the main stream)
+            if (c->mustWait) HIPCK(c, hipStreamWaitEvent(st, c->mustWait, 0));
+            c->poolHead = off + need; *offOut = off;
+            return 0;
+        }
+        if (c->inflight.empty()) return c->fail(CRT_ERR_DEVICE, "slab pool of %zu bytes cannot hold a launch of %zu bytes", c->poolBytes, need);
+        if (c->mustWait) c->freeEvents.push_back(c->mustWait);
+        c->mustWait = c->inflight.front().freed;
+        c->inflight.pop_front();
+    }
+}
+
 int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
 {
     if (!c) return CRT_ERR_INVALID;
@@ -487,60 +591,41 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     if (passes < 1 || passes > 4) return c->fail(CRT_ERR_INVALID, "passes must be 1..4 (the reference's UI range, renderer.cpp:178)");
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (c->tileCount == 0 || frames == 0) return CRT_OK;
-    const uint32_t maxF = (uint32_t)c->cfg.maxFramesPerLaunch;
-    const size_t need = (size_t)c->tileCount * 256u * (size_t)(frames < maxF ? frames : maxF) * passes * 16u;   // one launch's samples
     { int r = update_tile_order(c); if (r) return r; }
-    if (c->lanes.empty()) {
+    if (c->streams.empty()) {
         int n = c->cfg.renderStreams;
         if (n <= 0) n = 7;
         if (n > 16) n = 16;
         if (c->cfg.collectStats) n = 1;                       // per-tile clocks of a statistics context describe ONE launch
-        c->lanes.resize((size_t)n);
-        for (auto& l : c->lanes) {
-            HIPCK(c, hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
-            HIPCK(c, hipEventCreateWithFlags(&l.slabFree, hipEventDisableTiming));
-        }
+        c->streams.resize((size_t)n);
+        for (auto& st : c->streams) HIPCK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     }
-    // every lane's slab is sized up front (hipMalloc synchronises the device: doing it lazily would serialise the first launches)
-    if (need > c->lanes[0].bytes) {
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        for (auto& l : c->lanes) { HIPCK(c, hipStreamSynchronize(l.s)); if (l.slab) { HIPCK(c, hipFree(l.slab)); l.slab = nullptr; l.bytes = 0; } }
-        // never take more than half of the free HBM for slabs: fewer lanes (less overlap) instead of an allocation failure
-        size_t freeB = 0, totalB = 0;
-        HIPCK(c, hipMemGetInfo(&freeB, &totalB));
-        size_t fit = need ? (freeB / 2) / need : c->lanes.size();
-        if (fit < 1) fit = 1;
-        while (c->lanes.size() > fit) {
-            crt_ctx::Lane& l = c->lanes.back();
-            (void)hipEventDestroy(l.slabFree); (void)hipStreamDestroy(l.s);
-            c->lanes.pop_back();
-        }
-        for (auto& l : c->lanes) {
-            HIPCK(c, hipStreamSynchronize(l.s));
-            if (l.slab) { HIPCK(c, hipFree(l.slab)); l.slab = nullptr; l.bytes = 0; }
-            HIPCK(c, hipMalloc(&l.slab, need));
-            l.bytes = need; l.pendingFree = false;
-        }
-    }
+    uint32_t maxF = 0;
+    { int r = ensure_pool(c, frames, passes, &maxF); if (r) return r; }
+    const size_t windowBytes = (size_t)c->tileCount * 256u * 64u * passes * 16u;
     for (uint32_t f0 = 0; f0 < frames; f0 += maxF) {
         const uint32_t nf = (frames - f0 < maxF) ? frames - f0 : maxF;
-        crt_ctx::Lane& l = c->lanes[(size_t)(c->launchSeq++ % c->lanes.size())];
-        // the slab may still be read by the accumulate kernel of the launch that used this lane last
-        if (l.pendingFree) HIPCK(c, hipStreamWaitEvent(l.s, l.slabFree, 0));
-        EventPair ev; int r;
+        hipStream_t st = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
+        size_t off = 0; int r;
+        if ((r = take_region(c, (size_t)((nf + 63u) / 64u) * windowBytes, st, &off))) return r;
+        void* slab = c->pool + off;
+        EventPair ev;
         if ((r = take_event(c, c->evRender, &ev))) return r;
-        HIPCK(c, hipEventRecord(ev.a, l.s));
-        HIPCK(c, crt_launch_render(&c->hScene, l.slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, l.s));
-        HIPCK(c, hipEventRecord(ev.b, l.s));
+        HIPCK(c, hipEventRecord(ev.a, st));
+        HIPCK(c, crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, st));
+        HIPCK(c, hipEventRecord(ev.b, st));
         // ordered accumulation on the main stream (frame order = launch order), behind this launch
         HIPCK(c, hipStreamWaitEvent(c->stream, ev.b, 0));
         if ((r = take_event(c, c->evAcc, &ev))) return r;
         HIPCK(c, hipEventRecord(ev.a, c->stream));
-        HIPCK(c, crt_launch_accumulate(l.slab, c->dAcc, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, (uint32_t)c->cfg.width, nf * passes, c->stream));
+        HIPCK(c, crt_launch_accumulate(slab, c->dAcc, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, (uint32_t)c->cfg.width, nf, passes, c->stream));
         HIPCK(c, hipEventRecord(ev.b, c->stream));
-        HIPCK(c, hipEventRecord(l.slabFree, c->stream));
-        l.pendingFree = true;
+        crt_ctx::Region reg; reg.off = off; reg.bytes = (size_t)((nf + 63u) / 64u) * windowBytes;
+        if (c->freeEvents.empty()) HIPCK(c, hipEventCreateWithFlags(&reg.freed, hipEventDisableTiming));
+        else { reg.freed = c->freeEvents.back(); c->freeEvents.pop_back(); }
+        HIPCK(c, hipEventRecord(reg.freed, c->stream));
+        c->inflight.push_back(reg);
     }
     return CRT_OK;
 }
@@ -550,7 +635,7 @@ int crt_sync(crt_ctx* c)
     if (!c) return CRT_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipStreamSynchronize(c->stream));          // every render launch is followed by its accumulate on this stream
-    for (auto& l : c->lanes) HIPCK(c, hipStreamSynchronize(l.s));
+    for (auto st : c->streams) HIPCK(c, hipStreamSynchronize(st));
     return CRT_OK;
 }
 
@@ -640,7 +725,7 @@ int crt_get_timing(crt_ctx* c, crt_timing* out)
     if (!c || !out) return CRT_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    for (auto& l : c->lanes) HIPCK(c, hipStreamSynchronize(l.s));
+    for (auto st : c->streams) HIPCK(c, hipStreamSynchronize(st));
     memset(out, 0, sizeof(*out));
     for (auto& ev : c->evRender) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->render_kernel_ms += ms; }
     for (auto& ev : c->evAcc) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->resolve_kernel_ms += ms; }
@@ -661,12 +746,12 @@ int crt_get_tile_clocks(crt_ctx* c, uint64_t* out)
     return CRT_OK;
 }
 
-// diagnostic builds (-DCRT_STAMPS) only: 10 extra words per tile behind the tile clocks (not part of the public ABI)
+// diagnostic builds (-DCRT_STAMPS) only: 16 extra words per tile behind the tile clocks (not part of the public ABI)
 extern "C" int crt_debug_tile_stamps(crt_ctx* c, uint64_t* out)
 {
     if (!c || !out || !c->dTileClocks) return CRT_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->cfg.device));
-    HIPCK(c, hipMemcpyAsync(out, c->dTileClocks + 2 * (size_t)c->tileCount, (size_t)c->tileCount * 80, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(out, c->dTileClocks + 2 * (size_t)c->tileCount, (size_t)c->tileCount * 128, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
 }

@@ -75,12 +75,15 @@ __device__ float crt_expf(float x)
     float s1 = asf((uint32_t)(k1 + 127) << 23), s2 = asf((uint32_t)(k2 + 127) << 23);
     return p * s1 * s2;
 }
-__device__ float crt_atan_pos(float x)
+// The three range reductions of atan share ONE division site and the two of acos ONE square root: -(1/x) == (-1)/x,
+// x/1 == x and 1+x == 1-|x| (x < 0) are exact identities of IEEE arithmetic, so the values are those of the branchy form.
+__device__ __forceinline__ float crt_atan_pos(float x)
 {
-    float y0, t;
-    if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; t = -(1.0f / x); }
-    else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = (x - 1.0f) / (x + 1.0f); }
-    else { y0 = 0.0f; t = x; }
+    const bool big = x > 2.414213562373095f, mid = x > 0.4142135623730950f;
+    const float y0 = big ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.0f);
+    const float num = big ? -1.0f : (mid ? x - 1.0f : x);
+    const float den = big ? x : (mid ? x + 1.0f : 1.0f);
+    const float t = num / den;
     float z = t * t;
     float p = 8.05374449538e-2f;
     p = p * z - 1.38776856032e-1f;
@@ -89,20 +92,20 @@ __device__ float crt_atan_pos(float x)
     p = p * z * t + t;
     return y0 + p;
 }
-__device__ float crt_atan2f(float y, float x)
+__device__ __forceinline__ float crt_atan2f(float y, float x)
 {
-    if (x != x || y != y) return x + y;
-    uint32_t sy = asu(y) & 0x80000000u, sx = asu(x) & 0x80000000u;
-    float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-    float r;
+    const uint32_t sy = asu(y) & 0x80000000u, sx = asu(x) & 0x80000000u;
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
     const float inf = asf(0x7f800000u);
+    const float a = crt_atan_pos(ay / ax);
+    float r = sx ? (CRT_PI - a) : a;
+    if (ax == inf && ay == inf) r = sx ? 2.356194490192345f : 0.7853981633974483f;
+    if (ax == 0.0f) r = 1.5707963267948966f;
     if (ay == 0.0f) r = sx ? CRT_PI : 0.0f;
-    else if (ax == 0.0f) r = 1.5707963267948966f;
-    else if (ax == inf && ay == inf) r = sx ? 2.356194490192345f : 0.7853981633974483f;
-    else { float a = crt_atan_pos(ay / ax); r = sx ? (CRT_PI - a) : a; }
-    return asf(asu(r) | sy);
+    r = asf(asu(r) | sy);
+    return (x != x || y != y) ? x + y : r;
 }
-__device__ float crt_asin_small(float x)
+__device__ __forceinline__ float crt_asin_small(float x)
 {
     float z = x * x;
     float p = 4.2163199048e-2f;
@@ -113,13 +116,14 @@ __device__ float crt_asin_small(float x)
     p = p * z * x + x;
     return p;
 }
-__device__ float crt_acosf(float x)
+__device__ __forceinline__ float crt_acosf(float x)
 {
-    if (x != x) return x;
-    if (x > 1.0f || x < -1.0f) return asf(0x7fc00000u);
-    if (x > 0.5f) { float s = __builtin_sqrtf(0.5f * (1.0f - x)); return 2.0f * crt_asin_small(s); }
-    if (x < -0.5f) { float s = __builtin_sqrtf(0.5f * (1.0f + x)); return CRT_PI - 2.0f * crt_asin_small(s); }
-    return 1.5707963267948966f - crt_asin_small(x);
+    const bool hi = x > 0.5f, lo = x < -0.5f;
+    const float s = __builtin_sqrtf(0.5f * (1.0f - __builtin_fabsf(x)));
+    const float p = crt_asin_small((hi || lo) ? s : x);
+    float r = hi ? 2.0f * p : (lo ? CRT_PI - 2.0f * p : 1.5707963267948966f - p);
+    if (x > 1.0f || x < -1.0f) r = asf(0x7fc00000u);
+    return (x != x) ? x : r;
 }
 
 // RNG: WangHash seed + xorshift32 (template/tmplmath.cpp:5-16, 27-34)
@@ -136,6 +140,14 @@ __device__ __forceinline__ float rnd(uint32_t& s)
 
 
 struct Hit { float t, u, v; int objIdx, triIdx; };
+#ifdef CRT_DUP
+// diagnostic build (-DCRT_DUP=n): region n of the SHADE phase is evaluated a second time on laundered copies of its inputs and the
+// result is kept alive, so the difference in SQ_INSTS_VALU against the normal build is that region's dynamic cost.  Never shipped.
+__device__ __forceinline__ float lnd(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ f3 lnd3(f3 v) { return mk3(lnd(v.x), lnd(v.y), lnd(v.z)); }
+__device__ __forceinline__ void sink(float x) { asm volatile("" :: "v"(x)); }
+__device__ __forceinline__ void sink3(f3 v) { sink(v.x); sink(v.y); sink(v.z); }
+#endif
 struct Cnt { uint32_t rays, primary, interior, leaf, tri, tlas, visits, meshhits; };
 
 typedef float rec4 __attribute__((ext_vector_type(4)));     // a fetched 16-byte piece of a record (native vector: usable as an asm operand)
@@ -196,24 +208,35 @@ __device__ __forceinline__ void hit_tri(rec4 a, rec4 b, rec4 c, f3 O, f3 D, Hit&
 // tests before the acceleration structure (file_scene.cpp:170-175)
 __device__ __forceinline__ void hit_light_floor(const Scene& sc, f3 O, f3 D, Hit& h)
 {
+    // Scene::lightAxis / floorAxisY (set at upload): the quad's invT has an identity rotation block / the plane's normal is exactly
+    // (0,1,0) — what FileScene and TLASFileScene always build (file_scene.cpp:15-19).  Then 1*x == x and the 0*x terms only add
+    // zeros, so the general expressions reduce to the short ones below; the two can differ in the SIGN OF A ZERO only, which no
+    // comparison here can see and which never reaches an accepted t (accepted hits have a non-zero numerator and denominator).
     {
         const float* c = sc.lightInvT;
-        const float Oy = c[4] * O.x + c[5] * O.y + c[6] * O.z + c[7];
-        const float Dy = c[4] * D.x + c[5] * D.y + c[6] * D.z;
+        float Oy, Dy;
+        if (sc.lightAxis) { Oy = O.y + c[7]; Dy = D.y; }
+        else { Oy = c[4] * O.x + c[5] * O.y + c[6] * O.z + c[7]; Dy = c[4] * D.x + c[5] * D.y + c[6] * D.z; }
         const float t = Oy / -Dy;
         if (t < h.t && t > 0) {
-            const float Ox = c[0] * O.x + c[1] * O.y + c[2] * O.z + c[3];
-            const float Oz = c[8] * O.x + c[9] * O.y + c[10] * O.z + c[11];
-            const float Dx = c[0] * D.x + c[1] * D.y + c[2] * D.z;
-            const float Dz = c[8] * D.x + c[9] * D.y + c[10] * D.z;
+            float Ox, Oz, Dx, Dz;
+            if (sc.lightAxis) { Ox = O.x + c[3]; Oz = O.z + c[11]; Dx = D.x; Dz = D.z; }
+            else {
+                Ox = c[0] * O.x + c[1] * O.y + c[2] * O.z + c[3];
+                Oz = c[8] * O.x + c[9] * O.y + c[10] * O.z + c[11];
+                Dx = c[0] * D.x + c[1] * D.y + c[2] * D.z;
+                Dz = c[8] * D.x + c[9] * D.y + c[10] * D.z;
+            }
             const float Ix = Ox + t * Dx, Iz = Oz + t * Dz;
             const float size = sc.lightSize;
             if (Ix > -size && Ix < size && Iz > -size && Iz < size) { h.t = t; h.objIdx = 0; }
         }
     }
     {
-        const f3 N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
-        const float t = -(dot3(O, N) + sc.floorD) / (dot3(D, N));
+        float num, den;
+        if (sc.floorAxisY) { num = O.y + sc.floorD; den = D.y; }
+        else { const f3 N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]); num = dot3(O, N) + sc.floorD; den = dot3(D, N); }
+        const float t = -num / den;
         if (t < h.t && t > 0) { h.t = t; h.objIdx = 1; }
     }
 }
@@ -320,89 +343,6 @@ __device__ __forceinline__ f3 sky_color(const Scene& sc, f3 D)
     return tex_sample(sc, sc.skyOffset, sc.skyW, sc.skyH, phi * CRT_INV2PI, theta * CRT_INVPI);
 }
 
-// One bounce of Renderer::Sample ("3. PathTracer/renderer.cpp":50-100) after FindNearest.  (s0..s3) = the hit
-// triangle's ShadeTri, fetched when the traversal finished.  Returns true when the path ends (L = terminal radiance);
-// otherwise writes the throughput factor of this depth and the continuation ray.
-__device__ __forceinline__ bool shade(const Scene& sc, const Hit& h, rec4 s0, rec4 s1, rec4 s2, rec4 s3,
-                                      f3& O, f3& D, f3& rD, bool& inside, int depth, uint32_t& seed, f3& factor, f3& L)
-{
-    if (h.objIdx == -1) { L = sky_color(sc, D); return true; }
-    if (depth >= sc.depthLimit) { L = mk3(0, 0, 0); return true; }
-    if (h.objIdx == 0) { L = mk3(24, 24, 22); return true; }        // light: GetLightColor (file_scene.cpp:164-167)
-    f3 I = O + h.t * D;
-    f3 N; float tu = 0, tv = 0; Material m;
-    if (h.objIdx == 1) {                                              // floor: Plane::GetNormal / GetUV (primitives.h:112-133)
-        N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
-        if (N.y == 1) {
-            float u = I.x, v = I.z;
-            u *= sc.floorInvto; v *= sc.floorInvto;
-            tu = u - __builtin_floorf(u); tv = v - __builtin_floorf(v);
-        }
-        m = sc.floorMat;
-    } else {                                                          // mesh: GetNormal / GetUV (bvh.cpp:290-305, blas_bvh.cpp:391-406)
-        const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
-        const float w = 1 - h.u - h.v;
-        const f3 Nn = w * n0 + h.u * n1 + h.v * n2;
-        tu = w * s2.y + h.u * s2.w + h.v * s3.y;
-        tv = w * s2.z + h.u * s3.x + h.v * s3.z;
-        const rec4* mp = reinterpret_cast<const rec4*>(sc.mats + (int)asu(s3.w));
-        const rec4 m0 = mp[0], m1 = mp[1];
-        m.reflectivity = m0.x; m.refractivity = m0.y; m.absorption[0] = m0.z; m.absorption[1] = m0.w; m.absorption[2] = m1.x;
-        m.texOffset = asu(m1.y); m.texW = (int)asu(m1.z); m.texH = (int)asu(m1.w);
-        if (sc.kind == 0) {
-            N = normalize3(Nn);
-        } else {
-            const uint32_t io = sc.instOff + (uint32_t)(h.objIdx - 2) * 128u + 64u;   // Instance::T rows
-            const rec4 r0 = ldg(sc.geom, io), r1 = ldg(sc.geom, io + 16), r2 = ldg(sc.geom, io + 32);
-            f3 Nt = mk3(r0.x * Nn.x + r0.y * Nn.y + r0.z * Nn.z + r0.w * 0.0f,
-                        r1.x * Nn.x + r1.y * Nn.y + r1.z * Nn.z + r1.w * 0.0f,
-                        r2.x * Nn.x + r2.y * Nn.y + r2.z * Nn.z + r2.w * 0.0f);
-            N = normalize3(Nt);
-        }
-    }
-    if (dot3(N, D) > 0) N = -N;
-    f3 albedo = (m.texW > 0) ? tex_sample(sc, m.texOffset, m.texW, m.texH, tu, tv) : mk3(1.0f, 1.0f, 1.0f);
-    f3 medium = mk3(1, 1, 1);
-    if (inside) {
-        f3 ab = mk3(m.absorption[0], m.absorption[1], m.absorption[2]) * -h.t;
-        medium = mk3(crt_expf(ab.x), crt_expf(ab.y), crt_expf(ab.z));
-    }
-    float r = rnd(seed);
-    f3 R;
-    bool newInside = false;
-    if (r < m.reflectivity) {                                         // HandleMirror, renderer.cpp:20-25
-        R = D - 2.0f * N * dot3(N, D);
-        factor = albedo * medium;
-    } else if (r < m.reflectivity + m.refractivity) {                 // HandleDielectric, renderer.cpp:27-45
-        R = D - 2.0f * N * dot3(N, D);
-        float n1 = inside ? 1.2f : 1, n2 = inside ? 1 : 1.2f;
-        float eta = n1 / n2, cosi = dot3(-D, N);
-        float cost2 = 1.0f - eta * eta * (1 - cosi * cosi);
-        if (cost2 > 0) {
-            float a = n1 - n2, b = n1 + n2, R0 = (a * a) / (b * b), c = 1 - cosi;
-            float Fr = R0 + (1 - R0) * (c * c * c * c * c);
-            f3 T = eta * D + ((eta * cosi - __builtin_sqrtf(__builtin_fabsf(cost2))) * N);
-            if (rnd(seed) > Fr) { R = T; newInside = !inside; }
-        }
-        factor = albedo * medium;
-    } else {                                                          // diffuse, renderer.cpp:93-99; tmplmath.h:535-544
-        f3 Rr;
-        do {
-            float rz = rnd(seed) * 2 - 1;                             // draw order pinned z, y, x
-            float ry = rnd(seed) * 2 - 1;
-            float rx = rnd(seed) * 2 - 1;
-            Rr = mk3(rx, ry, rz);
-        } while (dot3(Rr, Rr) > 1);
-        if (dot3(Rr, N) < 0) Rr = Rr * -1.0f;
-        R = normalize3(Rr);
-        f3 brdf = albedo * CRT_INVPI;
-        factor = medium * brdf * 2.0f * CRT_PI * dot3(R, N);
-    }
-    O = I + R * CRT_EPS; D = R; rD = mk3(1 / R.x, 1 / R.y, 1 / R.z);
-    inside = newInside;
-    return false;
-}
-
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -411,7 +351,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 
 // ------------------------------------------------------------------------------------------------------------
 // render_tiles_kernel<KIND, COUNT>: grid = tiles owned by this ctx, block = one wavefront (lane = frame).
-// slab layout: float4 [tileLocal][pixel 0..255][sample 0..S), S = frames*passes, sample = frame*passes + pass
+// slab layout: float4 [window][tileLocal][sample 0..S)[pixel 0..255], S = frames*passes of the window, sample = frame*passes + pass
+// (sample-major inside a tile: accumulate_kernel's 256 threads read 4 KB rows; the stores here are scattered either way)
 //
 // Per-lane traversal state is ONE packed reference `cur` (layout.h), the 64-byte record it names — already
 // PRE-LOADED into registers q0..q3 by the trip that produced it — and a stack whose top lives in a register:
@@ -442,7 +383,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                                                            Counters* __restrict__ counters, unsigned long long* __restrict__ tileClocks,
                                                            const uint32_t* __restrict__ tileOrder,
                                                            uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
-                                                           uint32_t sppFirst, uint32_t frames, uint32_t passes)
+                                                           uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t windows)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -452,9 +393,16 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     // round-robin over the 8 XCDs / 256 CUs instead of piling up on the XCDs that own the image rows of the model.  The
     // geometry fits every XCD's L2, so nothing is lost by not giving an XCD a contiguous run of tiles (measured: a
     // contiguous-per-XCD mapping is 7-14 % slower).  Speed only; any bijection gives the same image.
-    const uint32_t b = blockIdx.x;
-    if (b >= tileCount) return;
-    const uint32_t tl = tileOrder ? tileOrder[b] : b;
+    // One launch covers `windows` consecutive 64-frame windows of the progressive render (block = (tile rank, window), rank-major):
+    // all windows of the expensive tiles are dispatched first and the cheap tiles fill the machine behind them, so a long job is
+    // one grid whose duration is total work / machine throughput instead of a sequence of launches that each end on their
+    // heaviest tile.
+    const uint32_t rank = blockIdx.x / windows, win = blockIdx.x - rank * windows;
+    if (rank >= tileCount) return;
+    const uint32_t tl = tileOrder ? tileOrder[rank] : rank;
+    sppFirst += win * 64u * passes;
+    frames = (frames - win * 64u < 64u) ? frames - win * 64u : 64u;               // frames of THIS window (the last one may be partial)
+    slab += (size_t)win * ((size_t)tileCount * 256u * 64u * passes);              // this window's region of the sample slab
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     uint32_t* stk = lds + lane;
@@ -464,7 +412,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     uint32_t trips = 0;
 #ifdef CRT_STAMPS
     // diagnostic build (-DCRT_STAMPS): shader-clock time per phase of this wave; never compiled into the product
-    unsigned long long stT[6] = {0, 0, 0, 0, 0, 0}; uint32_t stN[4] = {0, 0, 0, 0};
+    unsigned long long stT[6] = {0, 0, 0, 0, 0, 0}; uint32_t stN[4] = {0, 0, 0, 0}; uint32_t stL[4] = {0, 0, 0, 0};
 #define CRT_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
 #else
 #define CRT_STAMP(var)
@@ -509,7 +457,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
         const bool runTlas = nTlas > 0;
         const bool runTri = nTri >= CRT_TRI_BATCH || (nTri > 0 && nNode + nTlas == 0);
         const bool runShade = nDone >= CRT_SHADE_BATCH || (nDone > 0 && !runNode && !runTlas && !runTri);
-        bool moved = false;
         // The record loads issued at the end of the previous trip are first needed here.  Naming all four tuples in one
         // empty asm keeps the register allocator from splitting a loaded tuple across the back-edge (it otherwise copies one
         // component right behind the loads, which puts a vmcnt wait — the whole fetch latency — at the end of every trip).
@@ -519,54 +466,201 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CRT_STAMP(s1);
         stT[0] += s1 - s0;
-        if (runShade) stN[0]++; if (runNode) stN[1]++; if (runTri) stN[2]++;
+        if (runShade) { stN[0]++; stL[0] += nDone; } if (runNode) { stN[1]++; stL[1] += nNode; } if (runTri) { stN[2]++; stL[2] += nTri; }
+        stN[3]++;
 #endif
 
         if (runShade && isDone) {
-            // ---------------- SHADE / RAY-GEN phase --------------------------------------------------------------
-            bool gen = fresh;
-            if (!fresh) {
-                if (h.objIdx >= 2) cn.meshhits++;
-                f3 factor, L;
-                const bool done = shade(sc, h, q0, q1, q2, q3, O, D, rD, inside, depth, seed, factor, L);
-                if (!done) {
-                    if (depth == 0) F0 = factor; else if (depth == 1) F1 = factor; else if (depth == 2) F2 = factor;
-                    else if (depth == 3) F3 = factor; else F4 = factor;
-                    depth++;
-                } else {
-                    // unwind the recursion: innermost factor first (albedo*medium*Sample(...) multiplies on return)
-                    if (depth > 4) L = F4 * L;
-                    if (depth > 3) L = F3 * L;
-                    if (depth > 2) L = F2 * L;
-                    if (depth > 1) L = F1 * L;
-                    if (depth > 0) L = F0 * L;
-                    uint32_t pix = item, pass = 0;
-                    if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
-                    slab[((size_t)tl * 256u + pix) * S + (size_t)lane * passes + pass] = make_float4(L.x, L.y, L.z, 0.0f);
-                    item++;
-                    gen = true;
-                    if (item >= items) { live = false; gen = false; }
+            // ---------------- SHADE / RAY-GEN phase: one step of Renderer::Sample ("3. PathTracer/renderer.cpp":50-100) ----------
+            // Written as a sequence of stages that as many lanes as possible share, instead of one if/else tree per outcome: the
+            // sky / floor / mesh texel fetch is ONE site, the direction normalisation of a diffuse bounce and of a new primary ray
+            // is ONE site, and the new ray's reciprocal direction, quad / plane tests and root step are ONE site.  Every lane
+            // still evaluates exactly the reference's expressions in the reference's order.
+            // stage 1: what did FindNearest return (renderer.cpp:52-55, 69)
+            const bool first = fresh;                                             // no path yet: only generate the first primary ray
+            const bool miss = !first && h.objIdx == -1;                           // -> GetSkyColor
+            const bool stop = !first && h.objIdx != -1 && (depth >= sc.depthLimit || h.objIdx == 0);   // depth limit -> 0, light -> (24,24,22)
+            const bool surf = !first && !miss && !stop;                           // floor or mesh: the path bounces
+            if (!first && h.objIdx >= 2) cn.meshhits++;
+            // stage 2: texture coordinates + surface data
+            float tu = 0, tv = 0; uint32_t tOff = sc.skyOffset; int tW = sc.skyW, tH = sc.skyH;
+            f3 I = O, N = O, absorb = O; float refl = 0, refr = 0;
+            if (miss) {                                                           // GetSkyColor, file_scene.cpp:142-154
+                const float phi = crt_atan2f(-D.z, D.x) + CRT_PI, theta = crt_acosf(-D.y);
+                tu = phi * CRT_INV2PI; tv = theta * CRT_INVPI;
+#if defined(CRT_DUP) && CRT_DUP == 1
+                { const f3 d2 = lnd3(D); sink(crt_atan2f(-d2.z, d2.x) + CRT_PI); sink(crt_acosf(-d2.y)); }
+#endif
+            }
+            if (surf) {
+                I = O + h.t * D;
+                if (h.objIdx == 1) {                                              // floor: Plane::GetNormal / GetUV (primitives.h:112-133)
+                    N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
+                    if (N.y == 1) {
+                        float u = I.x, v = I.z;
+                        u *= sc.floorInvto; v *= sc.floorInvto;
+                        tu = u - __builtin_floorf(u); tv = v - __builtin_floorf(v);
+                    }
+                    refl = sc.floorMat.reflectivity; refr = sc.floorMat.refractivity;
+                    absorb = mk3(sc.floorMat.absorption[0], sc.floorMat.absorption[1], sc.floorMat.absorption[2]);
+                    tOff = sc.floorMat.texOffset; tW = sc.floorMat.texW; tH = sc.floorMat.texH;
+                } else {                                                          // mesh: GetNormal / GetUV (bvh.cpp:290-305, blas_bvh.cpp:391-406)
+                    const f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q0.w, q1.x, q1.y), n2 = mk3(q1.z, q1.w, q2.x);   // (q0..q3) = the hit's ShadeTri
+                    const float w = 1 - h.u - h.v;
+                    const f3 Nn = w * n0 + h.u * n1 + h.v * n2;
+                    tu = w * q2.y + h.u * q2.w + h.v * q3.y;
+                    tv = w * q2.z + h.u * q3.x + h.v * q3.z;
+                    const rec4* mp = reinterpret_cast<const rec4*>(sc.mats + (int)asu(q3.w));
+                    const rec4 m0 = mp[0], m1 = mp[1];
+                    refl = m0.x; refr = m0.y; absorb = mk3(m0.z, m0.w, m1.x);
+                    tOff = asu(m1.y); tW = (int)asu(m1.z); tH = (int)asu(m1.w);
+                    if (KIND == 0) {
+                        N = normalize3(Nn);
+                    } else {
+                        const uint32_t io = sc.instOff + (uint32_t)(h.objIdx - 2) * 128u + 64u;   // Instance::T rows
+                        const rec4 r0 = ldg(geom, io), r1 = ldg(geom, io + 16), r2 = ldg(geom, io + 32);
+                        N = normalize3(mk3(r0.x * Nn.x + r0.y * Nn.y + r0.z * Nn.z + r0.w * 0.0f,
+                                           r1.x * Nn.x + r1.y * Nn.y + r1.z * Nn.z + r1.w * 0.0f,
+                                           r2.x * Nn.x + r2.y * Nn.y + r2.z * Nn.z + r2.w * 0.0f));
+                    }
+                }
+                if (dot3(N, D) > 0) N = -N;
+            }
+            // stage 3: the one texel fetch (Texture::Sample) — sky colour of a miss, albedo of a textured surface
+            f3 c = mk3(1.0f, 1.0f, 1.0f);
+            if (miss || (surf && tW > 0)) c = tex_sample(sc, tOff, tW, tH, tu, tv);
+#if defined(CRT_DUP) && CRT_DUP == 2
+            if (miss || (surf && tW > 0)) sink3(tex_sample(sc, tOff, tW, tH, lnd(tu), lnd(tv)));
+#endif
+#if defined(CRT_DUP) && CRT_DUP == 10
+            if (surf && h.objIdx >= 2) { const float w = 1 - lnd(h.u) - h.v; const f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q0.w, q1.x, q1.y), n2 = mk3(q1.z, q1.w, q2.x);
+                sink3(normalize3(w * n0 + h.u * n1 + h.v * n2)); sink(w * q2.y + h.u * q2.w + h.v * q3.y); sink(w * q2.z + h.u * q3.x + h.v * q3.z); }
+#endif
+            // stage 4a: the bounce (renderer.cpp:76-99).  `v` = outgoing direction (a diffuse one still to be normalised), `pre` = the
+            // throughput factor without the cosine term of the diffuse branch
+            f3 v = O, pre = O; bool norm = false, diffuse = false, newInside = false;
+            if (surf) {
+                f3 medium = mk3(1, 1, 1);
+                if (inside) {
+                    const f3 ab = absorb * -h.t;
+                    medium = mk3(crt_expf(ab.x), crt_expf(ab.y), crt_expf(ab.z));
+                }
+                const float r = rnd(seed);
+                if (r < refl) {                                                   // HandleMirror, renderer.cpp:20-25
+                    v = D - 2.0f * N * dot3(N, D);
+                    pre = c * medium;
+                } else if (r < refl + refr) {                                     // HandleDielectric, renderer.cpp:27-45
+                    v = D - 2.0f * N * dot3(N, D);
+                    const float n1 = inside ? 1.2f : 1, n2 = inside ? 1 : 1.2f;
+                    const float eta = n1 / n2, cosi = dot3(-D, N);
+                    const float cost2 = 1.0f - eta * eta * (1 - cosi * cosi);
+                    if (cost2 > 0) {
+                        const float a = n1 - n2, b2 = n1 + n2, R0 = (a * a) / (b2 * b2), cc = 1 - cosi;
+                        const float Fr = R0 + (1 - R0) * (cc * cc * cc * cc * cc);
+                        const f3 T = eta * D + ((eta * cosi - __builtin_sqrtf(__builtin_fabsf(cost2))) * N);
+                        if (rnd(seed) > Fr) { v = T; newInside = !inside; }
+                    }
+                    pre = c * medium;
+                } else {                                                          // diffuse, renderer.cpp:93-99; diffusereflection tmplmath.h:535-544
+                    f3 Rr;
+                    do {
+                        const float rz = __builtin_fmaf(rnd(seed), 2.0f, -1.0f);   // draw order pinned z, y, x; r*2 is exact,
+                        const float ry = __builtin_fmaf(rnd(seed), 2.0f, -1.0f);   // so the fused form rounds once exactly like r*2-1
+                        const float rx = __builtin_fmaf(rnd(seed), 2.0f, -1.0f);
+                        Rr = mk3(rx, ry, rz);
+                    } while (dot3(Rr, Rr) > 1);
+#if defined(CRT_DUP) && CRT_DUP == 7
+                    { uint32_t s2 = seed ^ 0x9e3779b9u; f3 R2; do { const float rz = rnd(s2) * 2 - 1, ry = rnd(s2) * 2 - 1, rx = rnd(s2) * 2 - 1; R2 = mk3(rx, ry, rz); } while (dot3(R2, R2) > 1); sink3(R2); }
+#endif
+                    if (dot3(Rr, N) < 0) Rr = Rr * -1.0f;
+                    v = Rr; norm = true; diffuse = true;
+                    const f3 brdf = c * CRT_INVPI;
+                    pre = medium * brdf * 2.0f * CRT_PI;                          // ... * dot(R, N) once R is normalised (stage 5)
                 }
             }
-            if (gen) {
+            // stage 4b: the path ended: unwind the recursion (innermost factor first: albedo*medium*Sample(...) multiplies on return),
+            // store the sample, move on to the stream's next pixel
+            bool gen = first;
+            if (miss || stop) {
+                f3 L = miss ? c : ((depth >= sc.depthLimit) ? mk3(0, 0, 0) : mk3(24, 24, 22));   // GetLightColor, file_scene.cpp:164-167
+                if (depth > 4) L = F4 * L;
+                if (depth > 3) L = F3 * L;
+                if (depth > 2) L = F2 * L;
+                if (depth > 1) L = F1 * L;
+                if (depth > 0) L = F0 * L;
+#if defined(CRT_DUP) && CRT_DUP == 8
+                { f3 L2 = lnd3(c); if (depth > 4) L2 = F4 * L2; if (depth > 3) L2 = F3 * L2; if (depth > 2) L2 = F2 * L2; if (depth > 1) L2 = F1 * L2; if (depth > 0) L2 = F0 * L2; sink3(L2); }
+#endif
+                uint32_t pix = item, pass = 0;
+                if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
+                slab[((size_t)tl * S + (lane * passes + pass)) * 256u + pix] = make_float4(L.x, L.y, L.z, 0.0f);
+                item++;
+                gen = true;
+                if (item >= items) { live = false; gen = false; }
+            }
+            if (gen) {                                                            // ProcessTile + Camera::GetPrimaryRay (renderer.cpp:125-126, camera.h:23-30)
                 const uint32_t pix = (passes == 1u) ? item : item / passes;
                 const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
                 const float jy = rnd(seed);                                       // pinned: first draw is the y jitter
                 const float jx = rnd(seed);
-                const float u = ((float)x + jx) * sc.invW, v = ((float)y + jy) * sc.invH;   // camera.h:23-30
-                const f3 P = TL + u * (TR - TL) + v * (BL - TL);
-                O = camPos; D = normalize3(P - camPos); rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
+                const float u = ((float)x + jx) * sc.invW, vv = ((float)y + jy) * sc.invH;
+                const f3 P = TL + u * (TR - TL) + vv * (BL - TL);
+                v = P - camPos; norm = true;
+#if defined(CRT_DUP) && CRT_DUP == 9
+                { uint32_t s2 = seed; const float jy2 = rnd(s2), jx2 = rnd(s2); const float u2 = ((float)x + jx2) * sc.invW, v2 = ((float)y + jy2) * sc.invH; sink3(TL + u2 * (TR - TL) + v2 * (BL - TL) - camPos); }
+#endif
                 inside = false; depth = 0; fresh = false;
                 cn.primary++;
             }
+            // stage 5: the new ray (bounce or primary) and the start of its scene.FindNearest: light quad, floor plane, root step
             if (live) {
-                // scene.FindNearest starts: light quad, floor plane, then the acceleration structure from its root
+                const float inv = 1.0f / __builtin_sqrtf(dot3(v, v));             // normalize(): v * (1 / sqrtf(dot(v, v)))
+                const f3 nv = norm ? v * inv : v;
+#if defined(CRT_DUP) && CRT_DUP == 5
+                { const f3 v2 = lnd3(v); sink3(v2 * (1.0f / __builtin_sqrtf(dot3(v2, v2)))); }
+#endif
+                if (surf) {
+                    const f3 factor = diffuse ? pre * dot3(nv, N) : pre;
+                    if (depth == 0) F0 = factor; else if (depth == 1) F1 = factor; else if (depth == 2) F2 = factor;
+                    else if (depth == 3) F3 = factor; else F4 = factor;
+                    depth++;
+                    O = I + nv * CRT_EPS; inside = newInside;
+                } else O = camPos;
+                D = nv; rD = mk3(1 / nv.x, 1 / nv.y, 1 / nv.z);
+#if defined(CRT_DUP) && CRT_DUP == 4
+                { const f3 n2 = lnd3(nv); sink3(mk3(1 / n2.x, 1 / n2.y, 1 / n2.z)); }
+#endif
                 cn.rays++;
                 h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
                 hit_light_floor(sc, O, D, h);
+#if defined(CRT_DUP) && CRT_DUP == 3
+                { Hit h2; h2.t = 1e34f; h2.u = 0; h2.v = 0; h2.objIdx = -1; h2.triIdx = -1; hit_light_floor(sc, lnd3(O), lnd3(D), h2); sink(h2.t); sink((float)h2.objIdx); }
+#endif
                 tO = O; tD = D; trD = rD; rayFinite = finite3(rD);
-                cur = sc.rootRef; sp = 0; moved = true;
-                if (COUNT && KIND == 0 && (cur & 0xC0000000u) == 0u) cn.leaf++;
+                sp = 0;
+                if (sc.rootIsPair) {
+                    // the root's two children travel in the kernel arguments (scalar registers): the first traversal step
+                    // (bvh.cpp:244-257 / tlas_bvh.cpp:96-110 at the root, empty stack) happens here, at this phase's lane
+                    // density, and a ray that misses both boxes never leaves the SHADE state
+                    const float* rp = sc.rootPair;
+                    const rec4 a0 = {rp[0], rp[1], rp[2], rp[3]}, a1 = {rp[4], rp[5], rp[6], rp[7]};
+                    const rec4 b0 = {rp[8], rp[9], rp[10], rp[11]}, b1 = {rp[12], rp[13], rp[14], rp[15]};
+                    float d1, d2;
+                    if (__ballot(!rayFinite) == 0ull) { d1 = box_fast(a0, a1, O, rD, h.t); d2 = box_fast(b0, b1, O, rD, h.t); }
+                    else { d1 = box_exact(a0, a1, O, rD, h.t); d2 = box_exact(b0, b1, O, rD, h.t); }
+#if defined(CRT_DUP) && CRT_DUP == 6
+                    { const f3 o2 = lnd3(O), r2 = lnd3(rD); sink(box_fast(a0, a1, o2, r2, h.t)); sink(box_fast(b0, b1, o2, r2, h.t)); }
+#endif
+                    const bool sw = d1 > d2;
+                    const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
+                    const uint32_t rn = sw ? asu(b0.w) : asu(a0.w), rf = sw ? asu(a0.w) : asu(b0.w);
+                    stk[0] = rf;                                                  // dead store unless pushed
+                    const bool hitN = dn != 1e30f;
+                    sp = (hitN && df != 1e30f) ? 1u : 0u;
+                    cur = hitN ? rn : kRefDone;
+                    if (COUNT) { if (KIND == 0) cn.interior++; else cn.tlas++; }
+                } else cur = sc.rootRef;
+                if (COUNT && KIND == 0 && (cur & 0xC0000000u) == 0u && cur != kRefDone) cn.leaf++;
             }
         }
 #ifdef CRT_STAMPS
@@ -595,7 +689,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                 sp = sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
             }
             if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
-            cur = next; moved = true;
+            cur = next;
         }
 #ifdef CRT_STAMPS
         CRT_STAMP(s3);
@@ -623,7 +717,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                     next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
                 }
                 if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
-                cur = next; moved = true;
+                cur = next;
             }
         }
 #ifdef CRT_STAMPS
@@ -644,7 +738,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                 next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
             }
             if (COUNT && !more && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
-            cur = next; moved = true;
+            cur = next;
         }
 #ifdef CRT_STAMPS
         CRT_STAMP(s5); stT[3] += s5 - s4;
@@ -669,13 +763,14 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     }
 #undef CRT_TOP
 
-    if (COUNT && tileClocks && lane == 0) {                 // instrumentation build only: per-tile wall time + loop trips
+    if (COUNT && tileClocks && lane == 0 && windows == 1u) {                 // instrumentation build only: per-tile wall time + loop trips
         tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
         tileClocks[2 * tl + 1] = trips;
 #ifdef CRT_STAMPS
-        unsigned long long* dbg = tileClocks + 2 * (size_t)tileCount + 10 * (size_t)tl;
+        unsigned long long* dbg = tileClocks + 2 * (size_t)tileCount + 16 * (size_t)tl;
         for (int i = 0; i < 6; i++) dbg[i] = stT[i];
         for (int i = 0; i < 4; i++) dbg[6 + i] = stN[i];
+        for (int i = 0; i < 4; i++) dbg[10 + i] = stL[i];
 #endif
     }
     // wave-level reduction of the counters, one atomic per counter per wave
@@ -689,23 +784,33 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// accumulate_kernel: accumulator[pixel] += slab samples, in sample (= frame, pass) order.  One thread per pixel of
-// the owned tiles; 64 consecutive threads = 4 pixel rows of one tile.
+// accumulate_kernel: accumulator[pixel] += the slab's samples in (window, frame, pass) order — the reference's
+// `accumulator[..] +=` order, renderer.cpp:124.  One 256-thread block per owned tile, one thread per pixel; every step of
+// the loop reads one 4 KB row of the slab (256 consecutive float4), so the kernel streams at HBM rate.  The adds of a pixel
+// stay in one thread, in order; eight loads are kept in flight ahead of them.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ slab, float4* __restrict__ acc,
                                                           uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
-                                                          uint32_t W, uint32_t S)
+                                                          uint32_t W, uint32_t frames, uint32_t passes)
 {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t tl = idx >> 8, pix = idx & 255u;
+    const uint32_t tl = blockIdx.x, pix = threadIdx.x;
     if (tl >= tileCount) return;
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t x = (tile % tilesX) * 16u + (pix & 15u), y = (tile / tilesX) * 16u + (pix >> 4);
-    const float4* s = slab + (size_t)idx * S;
+    const size_t winStride = (size_t)tileCount * 256u * 64u * passes;
     float4 a = acc[x + (size_t)y * W];
-    for (uint32_t i = 0; i < S; i++) {
-        const float4 v = s[i];
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    for (uint32_t f0 = 0; f0 < frames; f0 += 64u, slab += winStride) {
+        const uint32_t S = ((frames - f0 < 64u) ? frames - f0 : 64u) * passes;
+        const float4* __restrict__ s = slab + (size_t)tl * S * 256u + pix;
+        uint32_t i = 0;
+        for (; i + 8u <= S; i += 8u) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = s[(size_t)(i + k) * 256u];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+        }
+        for (; i < S; i++) { const float4 v = s[(size_t)i * 256u]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
     }
     acc[x + (size_t)y * W] = a;
 }
@@ -982,8 +1087,10 @@ extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::C
                                         uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
-    dim3 grid(tileCount), block(64);
-#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes)
+    const uint32_t windows = (frames + 63u) / 64u;                      // one 64-lane wavefront per (tile, 64-frame window)
+    if ((unsigned long long)tileCount * windows > 0x7fffffffull) return hipErrorInvalidValue;
+    dim3 grid(tileCount * windows), block(64);
+#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH(0, true); else CRT_LAUNCH(0, false); }
     else { if (collectStats) CRT_LAUNCH(1, true); else CRT_LAUNCH(1, false); }
 #undef CRT_LAUNCH
@@ -991,11 +1098,11 @@ extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::C
 }
 
 extern "C" hipError_t crt_launch_accumulate(const void* slab, void* acc, uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount,
-                                            uint32_t tilesX, uint32_t W, uint32_t S, hipStream_t stream)
+                                            uint32_t tilesX, uint32_t W, uint32_t frames, uint32_t passes, hipStream_t stream)
 {
-    if (tileCount == 0 || S == 0) return hipSuccess;
+    if (tileCount == 0 || frames == 0) return hipSuccess;
     dim3 grid(tileCount), block(256);
-    hipLaunchKernelGGL(crt::accumulate_kernel, grid, block, 0, stream, (const float4*)slab, (float4*)acc, tileFirst, tileStride, tileCount, tilesX, W, S);
+    hipLaunchKernelGGL(crt::accumulate_kernel, grid, block, 0, stream, (const float4*)slab, (float4*)acc, tileFirst, tileStride, tileCount, tilesX, W, frames, passes);
     return hipGetLastError();
 }
 

@@ -82,6 +82,9 @@ struct Scene {                            // passed to the kernels BY VALUE (ker
     uint32_t rootRef;                     // packed reference of the root (BVH node 0 / TLAS node 0)
     uint32_t stackDepth;                  // dwords per lane of the LDS traversal stack (BVH height + TLAS height + 1 marker + slack)
     uint32_t bvhStack;                    // of which the BVH part (find_nearest_kernel keeps the TLAS entries above it)
+    uint32_t lightAxis, floorAxisY;       // 1: light invT has an identity rotation block / floor normal is exactly (0,1,0): short quad / plane tests (kernels.hip)
+    uint32_t rootIsPair;                  // 1: rootPair holds the root's two children (always, unless the root itself is a leaf)
+    float rootPair[16];                   // NodePair of the root (BVH: its child pair; TLAS: its two child TlasNodes, same 2 x {lo, ref, hi, -} layout)
 };
 
 struct Counters { unsigned long long v[8]; };   // order = crt_counters

@@ -99,10 +99,12 @@ typedef struct crt_config {
     /* image tiles owned by this ctx: tile = tileFirst + i*tileStride, i in [0, tileCount); tileCount < 0 = all.
      * Tiles are numbered x-major as in Renderer::Tick (renderer.cpp:151-152).  Other pixels are never touched. */
     int32_t tileFirst, tileStride, tileCount;
-    int32_t maxFramesPerLaunch;  /* 0 = default (64): frames rendered per kernel launch = lanes of one wavefront        */
+    int32_t maxFramesPerLaunch;  /* frames rendered per kernel launch; 0 = default (4096 = 64 windows of 64 frames, one wavefront
+                                    per (tile, window)); values > 64 are rounded down to whole windows; the sample-slab pool
+                                    (at most half of the free HBM) may lower it                                            */
     int32_t collectStats;        /* !=0: kernels also count node iterations / triangle tests / BLAS visits / mesh hits   */
-    int32_t renderStreams;       /* HIP streams (each with its own sample slab) the 64-frame launches rotate over, so that
-                                    independent launches overlap on the GPU; 0 = default (7), 1 = strictly one launch at a time */
+    int32_t renderStreams;       /* HIP streams the render launches rotate over, so that independent launches (consecutive crt_render
+                                    calls, or the pieces of one long call) overlap on the GPU; 0 = default (7), 1 = one at a time */
 } crt_config;
 
 typedef struct crt_ray { float O[3]; float D[3]; int32_t inside; } crt_ray;
@@ -146,10 +148,14 @@ int  crt_set_camera(crt_ctx* ctx, const float camPos[3], const float topLeft[3],
 /* ---- rendering (upper seam: the tile loop of Renderer::Tick) --------------------------------------- */
 /* Renders `frames` consecutive Ticks: frame k uses spp = spp_first + k*passes for its tile seeds
  * (renderer.cpp:120,167) and adds passes samples per pixel into the accumulator in frame order.
- * Asynchronous: launches of up to 64 frames rotate over cfg.renderStreams HIP streams and overlap with those of earlier
- * crt_render calls; the accumulation order is kept by events.  crt_sync / any read waits for everything. */
+ * Asynchronous: the call is cut into launches of up to cfg.maxFramesPerLaunch frames (one grid covers all their 64-frame windows);
+ * launches rotate over cfg.renderStreams HIP streams and overlap with those of earlier crt_render calls; the accumulation order
+ * is kept by events.  crt_sync / any read waits for everything. */
 int  crt_render(crt_ctx* ctx, uint32_t spp_first, uint32_t frames, uint32_t passes);
 int  crt_sync(crt_ctx* ctx);
+/* Optional: sizes the device-side sample-slab pool for an upcoming crt_render(.., frames, passes) now (allocating tens of GB takes
+ * seconds and synchronises the device; without this call the first crt_render that needs a larger pool pays for it). */
+int  crt_reserve(crt_ctx* ctx, uint32_t frames, uint32_t passes);
 int  crt_clear(crt_ctx* ctx);                                   /* Renderer::ClearAccumulator (renderer.cpp:15-18)    */
 int  crt_read_accumulator(crt_ctx* ctx, float* host_rgba /* float4[width*height] */);
 /* screen->pixels and Renderer::energy as ProcessTile/Tick leave them (renderer.cpp:119,127-129,155-157):

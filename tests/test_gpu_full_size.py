@@ -128,7 +128,8 @@ def test_config5_4k_tile_split_property(crt):
 
 
 def test_config4_tower_1080p_256spp(crt, orc):
-    """BASELINE config 4: watch-tower.obj FileScene + textures, 1920x1080, 256 spp = 4 launches of 64 frames.
+    """BASELINE config 4: watch-tower.obj FileScene + textures, 1920x1080, 256 spp = ONE launch covering 4 windows of 64 frames
+    (bit-identical to 4 launches of one window each).
     1080 is not a multiple of 16: SCRHEIGHT/16 truncates (renderer.cpp:151), rows 1072..1079 stay untouched."""
     Wt, Ht, S = 1920, 1080, 256
     hs = crt.HostScene(scene_path("tower_scene.xml"), 0, ASSETS)
@@ -136,9 +137,14 @@ def test_config4_tower_1080p_256spp(crt, orc):
     hs.upload(ctx)
     ctx.render(1, S, 1)
     acc = ctx.accumulator()
-    assert ctx.timing()["render_launches"] == 4
+    assert ctx.timing()["render_launches"] == 1
     c = ctx.counters()
     assert c["primary"] == (Wt // 16) * (Ht // 16) * 256 * S
+    c1 = crt.Context(Wt, Ht, max_frames_per_launch=64)
+    hs.upload(c1)
+    c1.render(1, S, 1)
+    assert np.array_equal(c1.accumulator(), acc) and c1.timing()["render_launches"] == 4
+    c1.close()
     assert np.isfinite(acc).all() and not acc[1072:].any() and acc[:1072, :, :3].any()
     o, _ = orc.load_scene(scene_path("tower_scene.xml"), 0, ASSETS)
     o.renderer_init(Wt, Ht)

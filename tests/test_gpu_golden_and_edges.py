@@ -240,6 +240,30 @@ def test_renderer_facade_tick_semantics(crt, orc):
     assert np.array_equal(r.accumulator(), o.accumulator())
 
 
+def test_multi_window_launch_with_partial_last_window(crt, orc):
+    """one crt_render of 150 frames = ONE grid over 3 windows (64 + 64 + 22 frames, a wavefront per (tile, window)); with passes = 2 the
+    windows hold 128 samples per pixel.  Both against sequential oracle Ticks, and against window-by-window launches."""
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    for passes, frames in [(1, 150), (2, 70)]:
+        ctx = crt.Context(64, 48)
+        hs.upload(ctx)
+        ctx.render(1, frames, passes)
+        acc = ctx.accumulator()
+        assert ctx.timing()["render_launches"] == 1
+        o.renderer_init(64, 48)
+        o.set_params(5, passes)
+        o.reset_counters()
+        o.render(frames, 4)
+        assert np.array_equal(acc, o.accumulator()), passes
+        assert ctx.counters()["rays"] == o.counters()["rays"]
+        c1 = crt.Context(64, 48, max_frames_per_launch=64)
+        hs.upload(c1)
+        c1.render(1, frames, passes)
+        assert np.array_equal(c1.accumulator(), acc) and c1.timing()["render_launches"] == (frames + 63) // 64
+        ctx.close(); c1.close()
+
+
 @pytest.mark.parametrize("streams", [1, 3, 7])
 def test_back_to_back_renders_keep_frame_order(crt, orc, streams):
     """many asynchronous crt_render calls (they overlap on `streams` HIP streams) must accumulate in frame order:

@@ -33,7 +33,12 @@ for i in range(4):
 ctx.clear(); ctx.sync(); t0 = time.perf_counter()
 for i in range(56): ctx.render(1 + 64 * i, 64, 1)
 ctx.sync(); thr = (time.perf_counter() - t0) / 56 * 1e3
-print("single-launch %%.3f ms | pipelined %%.3f ms/step" %% (np.median(ts[1:]), thr))
+ctx.clear(); ctx.render(1, 64 * 64, 1); ctx.sync(); ctx.timing()
+ctx.clear(); ctx.sync(); t0 = time.perf_counter()
+ctx.render(1, 64 * 64, 1)
+ctx.sync(); job = (time.perf_counter() - t0) / 64 * 1e3
+tm = ctx.timing()
+print("single-launch %%.3f ms | 56 calls pipelined %%.3f ms/step | one 64-window job %%.3f ms/step (render kernel %%.1f ms, accumulate %%.1f ms, %%d launches)" %% (np.median(ts[1:]), thr, job, tm["render_kernel_ms"], tm["resolve_kernel_ms"], tm["render_launches"]))
 ''' % REPO
     scene = args[0] if args else "bunny_scene.xml"
     kind = args[1] if len(args) > 1 else "0"
