@@ -222,7 +222,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel": "render_tiles_kernel", "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-                     "job_achieved": round(rays / elapsed * (alg_bytes_launch / max(counts["rays"], 1)) / 1e9, 2),
+                     "job_achieved": round(rays / elapsed * (algorithmic_bytes(counts) / max(counts["rays"], 1)) / 1e9, 2),
                      "accumulate_kernel_ms_per_step": round(acc_ms / args.steps, 4),
                      "counters_per_step": {k: round(v) for k, v in counts.items()},
                      "note": "achieved = algorithmic bytes of one launch / its mean duration (HIP events on its stream); job_achieved = algorithmic GB/s over the whole timed region (incl. the ordered accumulate)"},

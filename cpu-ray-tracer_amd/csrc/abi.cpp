@@ -406,6 +406,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         const float* m = sd->lightInvT;
         s.lightAxis = (m[0] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f && m[5] == 1.0f && m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f && m[10] == 1.0f) ? 1u : 0u;
         s.floorAxisY = (sd->floorN[0] == 0.0f && sd->floorN[1] == 1.0f && sd->floorN[2] == 0.0f) ? 1u : 0u;
+        if (getenv("CRT_DEBUG_GENERAL_PRIMS")) s.lightAxis = s.floorAxisY = 0u;     // tests: the general quad / plane expressions on the standard scenes
     }
     s.floorMat = mats[1];
     s.skyOffset = texOff[sd->skyTexture]; s.skyW = sd->textures[sd->skyTexture].width; s.skyH = sd->textures[sd->skyTexture].height;
@@ -429,10 +430,11 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         memcpy(s.rootPair, geom.data() + ((size_t)(rootRef0 & crt::kRefOffsetMask) << 4), 64);
         s.rootIsPair = 1;
     }
+    if (getenv("CRT_DEBUG_NO_ROOTPAIR")) s.rootIsPair = 0;                            // tests: every ray starts at the root reference instead
     s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 3 : 0);   // + TLAS pushes + the return marker + slack
     c->ldsBytes = s.stackDepth * 64u * 4u;
     if (const char* e = getenv("CRT_DEBUG_EXTRA_LDS")) c->ldsBytes += (uint32_t)atoi(e);   // occupancy experiments only
-    if (c->ldsBytes > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "tree height %u (+TLAS %u) needs %u bytes of LDS traversal stack per wave (> 64 KiB)", maxHeight, tlasHeight, c->ldsBytes);
+    if (c->ldsBytes + 15u * 256u > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "tree height %u (+TLAS %u) needs %u bytes of LDS traversal stack per wave (> 64 KiB)", maxHeight, tlasHeight, c->ldsBytes);
     // world-space bounds of all meshes (FileScene: root box of the BVH; TLAS: root box of the TLAS) for the dispatch-order heuristic
     {
         float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};

@@ -374,9 +374,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 #ifndef CRT_TRI_BATCH
 #define CRT_TRI_BATCH 1
 #endif
+#ifndef CRT_NODE_BATCH
+#define CRT_NODE_BATCH 1
+#endif
 
 #ifndef CRT_MIN_WAVES
-#define CRT_MIN_WAVES 4      // waves per SIMD the register budget must allow (<= 128 VGPRs)
+#define CRT_MIN_WAVES 5      // waves per SIMD the register budget must allow (<= 96 VGPRs)
 #endif
 template <int KIND, bool COUNT>
 __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const Scene sc, float4* __restrict__ slab,
@@ -425,12 +428,16 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     const f3 BL = mk3(sc.bottomLeft[0], sc.bottomLeft[1], sc.bottomLeft[2]);
 
     bool live = lane < frames;
+    uint64_t liveMask = __builtin_amdgcn_ballot_w64(live);                    // lanes whose stream still has pixels to render
     uint32_t seed = init_seed(tx + ty * (uint32_t)sc.W + (sppFirst + lane * passes) * 1799u);   // renderer.cpp:120
     uint32_t item = 0;
     // world-space ray of the current path segment, its nearest hit so far, path state
     f3 O = camPos, D = camPos, rD = camPos; bool inside = false; int depth = 0;
     Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
-    f3 F0 = camPos, F1 = camPos, F2 = camPos, F3 = camPos, F4 = camPos;    // throughput factors of depths 0..4
+    // throughput factors of depths 0..4 (albedo*medium*... of each bounce, multiplied on unwind): written once per bounce and read once
+    // per path, so they live in a per-lane LDS column behind the traversal stack (component j of depth k at fst[(3k + j) * 64]) instead
+    // of 15 registers — the kernel then fits 5 waves per SIMD — and a bounce stores through a computed address instead of a select chain
+    float* fst = reinterpret_cast<float*>(lds + sc.stackDepth * 64u + lane);
     // traversal state; (tO, tD, trD) = ray in the space of the structure being walked (object space inside a BLAS)
     uint32_t cur = kRefDone, sp = 0;
     f3 tO = camPos, tD = camPos, trD = camPos;
@@ -445,18 +452,27 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 #define CRT_TOP() (stk[(sp ? sp - 1u : 0u) * 64u])
 
     for (;;) {
+        // state ballots: the compares write their lane masks straight into scalar registers; `liveMask` (maintained below) removes
+        // finished lanes with one scalar AND instead of a per-lane predicate round trip
+        const uint64_t mDone = __builtin_amdgcn_ballot_w64(cur == kRefDone) & liveMask;
+        const uint64_t mNode = __builtin_amdgcn_ballot_w64((cur & 0xC0000000u) == kRefInterior) & liveMask;
+        const uint64_t mTri = __builtin_amdgcn_ballot_w64(cur != kRefDone && (cur & 0xC0000000u) == 0u) & liveMask;
+        const uint64_t mTlas = (KIND == 1) ? (__builtin_amdgcn_ballot_w64((cur & kRefTlasBit) != 0u) & liveMask) : 0ull;
         const bool isDone = live && cur == kRefDone;
         const bool isNode = live && (cur & 0xC0000000u) == kRefInterior;
         const bool isTri = live && cur != kRefDone && (cur & 0xC0000000u) == 0u;
         const bool isTlas = (KIND == 1) && live && (cur & kRefTlasBit) != 0u;
-        const int nDone = __popcll(__ballot(isDone)), nNode = __popcll(__ballot(isNode)), nTri = __popcll(__ballot(isTri));
-        const int nTlas = (KIND == 1) ? __popcll(__ballot(isTlas)) : 0;
+        const int nDone = __popcll(mDone), nNode = __popcll(mNode), nTri = __popcll(mTri);
+        const int nTlas = (KIND == 1) ? __popcll(mTlas) : 0;
         if (nDone + nNode + nTri + nTlas == 0) break;
         if (COUNT) trips++;
-        const bool runNode = nNode > 0;
+        // a phase runs when enough lanes wait for it; when no phase reaches its batch size the most populated one runs
+        const bool bigNode = nNode >= CRT_NODE_BATCH, bigTri = nTri >= CRT_TRI_BATCH, bigShade = nDone >= CRT_SHADE_BATCH;
+        const bool none = !bigNode && !bigTri && !bigShade && nTlas == 0;
         const bool runTlas = nTlas > 0;
-        const bool runTri = nTri >= CRT_TRI_BATCH || (nTri > 0 && nNode + nTlas == 0);
-        const bool runShade = nDone >= CRT_SHADE_BATCH || (nDone > 0 && !runNode && !runTlas && !runTri);
+        const bool runNode = bigNode || (none && nNode > 0 && nNode >= nTri && nNode >= nDone);
+        const bool runTri = bigTri || (none && nTri > 0 && nTri > nNode && nTri >= nDone);
+        const bool runShade = bigShade || (none && nDone > 0 && nDone > nNode && nDone > nTri);
         // The record loads issued at the end of the previous trip are first needed here.  Naming all four tuples in one
         // empty asm keeps the register allocator from splitting a loaded tuple across the back-edge (it otherwise copies one
         // component right behind the loads, which puts a vmcnt wait — the whole fetch latency — at the end of every trip).
@@ -583,13 +599,15 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
             bool gen = first;
             if (miss || stop) {
                 f3 L = miss ? c : ((depth >= sc.depthLimit) ? mk3(0, 0, 0) : mk3(24, 24, 22));   // GetLightColor, file_scene.cpp:164-167
-                if (depth > 4) L = F4 * L;
-                if (depth > 3) L = F3 * L;
-                if (depth > 2) L = F2 * L;
-                if (depth > 1) L = F1 * L;
-                if (depth > 0) L = F0 * L;
+                {
+                    float F[15];
+#pragma unroll
+                    for (int k = 0; k < 15; k++) F[k] = fst[k * 64];              // all 15 reads issued together; levels >= depth are never used
+#pragma unroll
+                    for (int k = 4; k >= 0; k--) if (depth > k) L = mk3(F[3 * k], F[3 * k + 1], F[3 * k + 2]) * L;
+                }
 #if defined(CRT_DUP) && CRT_DUP == 8
-                { f3 L2 = lnd3(c); if (depth > 4) L2 = F4 * L2; if (depth > 3) L2 = F3 * L2; if (depth > 2) L2 = F2 * L2; if (depth > 1) L2 = F1 * L2; if (depth > 0) L2 = F0 * L2; sink3(L2); }
+                { f3 L2 = lnd3(c); for (int k = 4; k >= 0; k--) if (depth > k) L2 = mk3(fst[(3 * k) * 64], fst[(3 * k + 1) * 64], fst[(3 * k + 2) * 64]) * L2; sink3(L2); }
 #endif
                 uint32_t pix = item, pass = 0;
                 if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
@@ -621,8 +639,8 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 #endif
                 if (surf) {
                     const f3 factor = diffuse ? pre * dot3(nv, N) : pre;
-                    if (depth == 0) F0 = factor; else if (depth == 1) F1 = factor; else if (depth == 2) F2 = factor;
-                    else if (depth == 3) F3 = factor; else F4 = factor;
+                    float* fd = fst + depth * 192;                                // depth <= 4 here: a surface hit at depth >= depthLimit (<= 5) ended the path
+                    fd[0] = factor.x; fd[64] = factor.y; fd[128] = factor.z;
                     depth++;
                     O = I + nv * CRT_EPS; inside = newInside;
                 } else O = camPos;
@@ -646,7 +664,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                     const rec4 a0 = {rp[0], rp[1], rp[2], rp[3]}, a1 = {rp[4], rp[5], rp[6], rp[7]};
                     const rec4 b0 = {rp[8], rp[9], rp[10], rp[11]}, b1 = {rp[12], rp[13], rp[14], rp[15]};
                     float d1, d2;
-                    if (__ballot(!rayFinite) == 0ull) { d1 = box_fast(a0, a1, O, rD, h.t); d2 = box_fast(b0, b1, O, rD, h.t); }
+                    if (__builtin_amdgcn_ballot_w64(!rayFinite) == 0ull) { d1 = box_fast(a0, a1, O, rD, h.t); d2 = box_fast(b0, b1, O, rD, h.t); }
                     else { d1 = box_exact(a0, a1, O, rD, h.t); d2 = box_exact(b0, b1, O, rD, h.t); }
 #if defined(CRT_DUP) && CRT_DUP == 6
                     { const f3 o2 = lnd3(O), r2 = lnd3(rD); sink(box_fast(a0, a1, o2, r2, h.t)); sink(box_fast(b0, b1, o2, r2, h.t)); }
@@ -663,6 +681,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                 if (COUNT && KIND == 0 && (cur & 0xC0000000u) == 0u && cur != kRefDone) cn.leaf++;
             }
         }
+        if (runShade) liveMask = __builtin_amdgcn_ballot_w64(live);             // streams end only in the SHADE phase
 #ifdef CRT_STAMPS
         CRT_STAMP(s2); stT[1] += s2 - s1;
 #endif
@@ -696,7 +715,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 #endif
         if (runNode) {
             // ---------------- NODE phase (infra/bvh.cpp:244-257) -------------------------------------------------
-            const bool allFinite = __ballot(isNode && !rayFinite) == 0ull;
+            const bool allFinite = __builtin_amdgcn_ballot_w64(isNode && !rayFinite) == 0ull;
             if (isNode) {
                 if (COUNT) cn.interior++;
                 uint32_t top = CRT_TOP();                                            // speculative: lands during the slab arithmetic
@@ -1090,7 +1109,7 @@ extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::C
     const uint32_t windows = (frames + 63u) / 64u;                      // one 64-lane wavefront per (tile, 64-frame window)
     if ((unsigned long long)tileCount * windows > 0x7fffffffull) return hipErrorInvalidValue;
     dim3 grid(tileCount * windows), block(64);
-#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows)
+#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH(0, true); else CRT_LAUNCH(0, false); }
     else { if (collectStats) CRT_LAUNCH(1, true); else CRT_LAUNCH(1, false); }
 #undef CRT_LAUNCH

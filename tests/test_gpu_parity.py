@@ -75,3 +75,26 @@ def test_render_matches_oracle(crt, orc, xml, kind, W, H, frames):
     px, energy = ctx.resolve_screen(1.0 / (frames + 1))
     assert np.array_equal(px, o.screen())
     assert energy == o.energy()
+
+
+@pytest.mark.parametrize("switch", ["CRT_DEBUG_GENERAL_PRIMS", "CRT_DEBUG_NO_ROOTPAIR"])
+@pytest.mark.parametrize("xml,kind", [("bunny_scene.xml", 0), ("tlas_scene.xml", 1)])
+def test_general_code_paths_are_bit_identical(crt, monkeypatch, switch, xml, kind):
+    """The render kernel takes two shortcuts that crt_upload_scene enables per scene: the short quad / plane tests when the light
+    is an unrotated quad and the floor normal is (0,1,0) (what FileScene / TLASFileScene always build), and every ray's first
+    traversal step from the root's child pair held in the kernel arguments.  The debug switches force the general expressions /
+    the plain root start on the same scenes: image, ray count and traversal counters must not change by a bit."""
+    W, H, frames = 128, 96, 3
+    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    out = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv(switch, "1")
+        ctx = crt.Context(W, H, collect_stats=True)
+        hs.upload(ctx)                       # the switches are read by crt_upload_scene
+        ctx.render(1, frames, 1)
+        out.append((ctx.accumulator(), ctx.counters()))
+        ctx.close()
+    monkeypatch.delenv(switch)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]

@@ -25,7 +25,7 @@ for d in sorted(glob.glob(src + "/pmc_*")):
             agg[r["Kernel_Name"].split("(")[0].strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             for c, vals in v.items():
-                pmc[k][c] = dict(mean_per_dispatch=sum(vals) / len(vals), dispatches=len(vals))
+                pmc[k][c] = dict(mean_per_dispatch=sum(vals) / len(vals), max_dispatch=max(vals), dispatches=len(vals))
 json.dump(pmc, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 for name in ("bench.json", "bench_traced.json"):
     p = os.path.join(src, name)
@@ -35,15 +35,20 @@ for name in ("bench.json", "bench_traced.json"):
             open(os.path.join(dst, tag + "_" + name), "w").write(lines[-1] + "\n")
 rk = [k for k in pmc if "render_tiles_kernel" in k and "false" in k] or [k for k in pmc if "render_tiles_kernel" in k]
 if rk and "FETCH_SIZE" in pmc[rk[0]] and "WRITE_SIZE" in pmc[rk[0]]:
-    f = pmc[rk[0]]["FETCH_SIZE"]["mean_per_dispatch"] * 1024
-    w = pmc[rk[0]]["WRITE_SIZE"]["mean_per_dispatch"] * 1024
+    # bench.py's job is ONE launch over all its windows; its warm-up and latency probes are smaller launches of the same kernel,
+    # so the job's launch is the largest dispatch
+    f = pmc[rk[0]]["FETCH_SIZE"]["max_dispatch"] * 1024
+    w = pmc[rk[0]]["WRITE_SIZE"]["max_dispatch"] * 1024
     out = dict(kernel=rk[0], fetch_bytes_raw=f, write_bytes=w, render_tiles_kernel_bytes_per_launch=int(f + w),
                render_tiles_kernel_bytes_per_launch_fetch_x2=int(2 * f + w),
-               note="FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch; FETCH_SIZE not x2-corrected because the record fetches are divergent 16-B loads, not the calibrated wide streaming pattern",
+               note="FETCH_SIZE*1024 + WRITE_SIZE*1024 of the job's launch (largest dispatch); FETCH_SIZE not x2-corrected because the record fetches are divergent 16-B loads, not the calibrated wide streaming pattern",
                source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/collect_profiles.sh " + tag)
     if "TCC_HIT_sum" in pmc[rk[0]]:
-        h, m = pmc[rk[0]]["TCC_HIT_sum"]["mean_per_dispatch"], pmc[rk[0]]["TCC_MISS_sum"]["mean_per_dispatch"]
+        h, m = pmc[rk[0]]["TCC_HIT_sum"]["max_dispatch"], pmc[rk[0]]["TCC_MISS_sum"]["max_dispatch"]
         out["l2_hit_rate"] = h / (h + m)
+    ak = [k for k in pmc if "accumulate_kernel" in k]
+    if ak and "FETCH_SIZE" in pmc[ak[0]]:
+        out["accumulate_kernel_fetch_bytes_x2"] = int(2 * pmc[ak[0]]["FETCH_SIZE"]["max_dispatch"] * 1024)   # wide coalesced streaming reads: the guide's x2 correction applies
     json.dump(out, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     print(out)
 print("profiles written for", tag)
