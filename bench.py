@@ -194,11 +194,13 @@ def main():
     launches_per_step = launches / args.steps
     alg_bytes_launch = algorithmic_bytes(counts) / launches_per_step if launches_per_step > 0 else 0.0
     achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    traffic = None
+    traffic = None          # HBM bytes of the job's launch from the PMC passes (tools/collect_profiles.sh), only for the workload they were collected on
     pmc_path = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("render_tiles_kernel_bytes_per_launch")
+            t = json.load(open(pmc_path))
+            if t.get("workload") == [args.scene, args.kind, W, H, SPP, args.steps]:
+                traffic = t.get("render_tiles_kernel_bytes_per_launch")
         except Exception:
             traffic = None
     out = {

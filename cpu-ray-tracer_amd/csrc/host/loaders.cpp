@@ -330,6 +330,310 @@ Raw decodeTga(const std::string& d, const std::string& path)
     return r;
 }
 
+// ---- baseline JPEG ------------------------------------------------------------------------------------------------------
+// Sequential Huffman JPEG (SOF0 / SOF1, 8 bit, 1 or 3 components, any sampling factors, restart intervals).  A texture's texels must
+// be the ones the reference gets from stbi_load (template/texture.h:18), and JPEG leaves the arithmetic of the decoder open, so this
+// follows the arithmetic lib/stb_image.h uses, stage by stage:
+//   coefficients  (short)(value * quantiser)                                            stbi__jpeg_decode_block, :2182-2233
+//   inverse DCT   the 12-bit fixed-point "islow" butterfly, column pass rounded to 2 extra bits (+512 >> 10), row pass
+//                 +65536 + (128 << 17) >> 17, clamped                                   stbi__idct_block, :2393-2495
+//   upsampling    1x1 copy; 2x1 / 1x2 / 2x2 triangle filters (3:1 weights), anything else nearest; the row pairing of
+//                 load_jpeg_image's line0 / line1 / ystep walk                          :3411-3604, :3845-3893
+//   colour        YCbCr -> RGB in 20-bit fixed point with the 0xffff0000 mask on the Cb term of G; components tagged 'R','G','B', or an
+//                 Adobe APP14 transform 0 without a JFIF header, are taken as RGB         stbi__YCbCr_to_RGB_row :3606-3631, :3825
+// Progressive, arithmetic-coded, 12-bit and 4-component files are rejected with a message.
+struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, w2 = 0, h2 = 0, x = 0, y = 0, pred = 0; std::vector<uint8_t> plane; };
+struct JpegHuff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool present = false; };
+
+struct JpegBits {
+    const uint8_t* p; size_t size, pos; uint32_t acc = 0; int cnt = 0; int marker = 0;      // marker: the marker that ended the entropy-coded segment (0 = none yet)
+    void fill() {
+        while (cnt <= 24) {
+            uint32_t b = 0;
+            if (!marker && pos < size) {
+                b = p[pos++];
+                if (b == 0xFF) {
+                    int c = pos < size ? p[pos++] : 0xD9;
+                    while (c == 0xFF) c = pos < size ? p[pos++] : 0xD9;                    // fill bytes
+                    if (c != 0) { marker = c; b = 0; }                                      // a real marker: the segment ends, zeros follow
+                }
+            }
+            acc |= b << (24 - cnt); cnt += 8;
+        }
+    }
+    int bit() { if (cnt < 1) fill(); const int b = (int)(acc >> 31); acc <<= 1; cnt--; return b; }
+    int receive(int n) { if (n == 0) return 0; if (cnt < n) fill(); const int v = (int)(acc >> (32 - n)); acc <<= n; cnt -= n; return v; }
+    void reset() { acc = 0; cnt = 0; marker = 0; }
+};
+
+void jpegBuildHuff(JpegHuff& h, const std::string& path)
+{
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; l++) {                                    // canonical codes, ITU T.81 annex C / F.2.2.3
+        h.valptr[l] = k; h.mincode[l] = code;
+        code += h.bits[l]; k += h.bits[l];
+        h.maxcode[l] = h.bits[l] ? code - 1 : -1;
+        if (code > (1 << l)) fail(path + ": bad JPEG Huffman code lengths");
+        code <<= 1;
+    }
+    h.present = true;
+}
+
+int jpegDecodeSym(JpegBits& b, const JpegHuff& h, const std::string& path)
+{
+    int code = 0;
+    for (int l = 1; l <= 16; l++) {
+        code = (code << 1) | b.bit();
+        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+    fail(path + ": corrupt JPEG (bad Huffman code)");
+    return 0;
+}
+
+inline int jpegExtend(int v, int n) { return (n && v < (1 << (n - 1))) ? v - (1 << n) + 1 : v; }   // T.81 F.2.2.1 EXTEND
+
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+inline uint8_t clamp255(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+
+// one 8-point pass of the fixed-point inverse DCT: constants are round(c * 4096); returns the even part in x[0..3] and the odd part in t[0..3]
+inline void idct8(const int s[8], int x[4], int t[4])
+{
+    // (int)(c * 4096 + 0.5), truncating toward zero as the C conversion does for the negative ones
+    const int C0_5411 = 2217, Cm1_8477 = -7567, C0_7653 = 3135, C1_1758 = 4816, C0_2986 = 1223, C2_0531 = 8410, C3_0727 = 12586,
+              C1_5013 = 6149, Cm0_8999 = -3685, Cm2_5629 = -10497, Cm1_9615 = -8034, Cm0_3901 = -1597;
+    int p1 = (s[2] + s[6]) * C0_5411;
+    const int e2 = p1 + s[6] * Cm1_8477, e3 = p1 + s[2] * C0_7653;
+    const int e0 = (s[0] + s[4]) * 4096, e1 = (s[0] - s[4]) * 4096;
+    x[0] = e0 + e3; x[3] = e0 - e3; x[1] = e1 + e2; x[2] = e1 - e2;
+    int t0 = s[7], t1 = s[5], t2 = s[3], t3 = s[1];
+    int p3 = t0 + t2, p4 = t1 + t3; p1 = t0 + t3; int p2 = t1 + t2;
+    const int p5 = (p3 + p4) * C1_1758;
+    t0 *= C0_2986; t1 *= C2_0531; t2 *= C3_0727; t3 *= C1_5013;
+    p1 = p5 + p1 * Cm0_8999; p2 = p5 + p2 * Cm2_5629; p3 *= Cm1_9615; p4 *= Cm0_3901;
+    t[3] = t3 + p1 + p4; t[2] = t2 + p2 + p3; t[1] = t1 + p2 + p4; t[0] = t0 + p1 + p3;
+}
+
+void jpegIdct(uint8_t* out, int stride, const short d[64])
+{
+    int v[64];
+    for (int c = 0; c < 8; c++) {                                       // columns; a column whose AC terms are all zero is just its DC term * 4
+        if (!(d[c + 8] | d[c + 16] | d[c + 24] | d[c + 32] | d[c + 40] | d[c + 48] | d[c + 56])) {
+            const int dc = d[c] * 4;
+            for (int r = 0; r < 8; r++) v[c + 8 * r] = dc;
+            continue;
+        }
+        const int s[8] = {d[c], d[c + 8], d[c + 16], d[c + 24], d[c + 32], d[c + 40], d[c + 48], d[c + 56]};
+        int x[4], t[4]; idct8(s, x, t);
+        for (int k = 0; k < 4; k++) x[k] += 512;
+        v[c] = (x[0] + t[3]) >> 10; v[c + 56] = (x[0] - t[3]) >> 10;
+        v[c + 8] = (x[1] + t[2]) >> 10; v[c + 48] = (x[1] - t[2]) >> 10;
+        v[c + 16] = (x[2] + t[1]) >> 10; v[c + 40] = (x[2] - t[1]) >> 10;
+        v[c + 24] = (x[3] + t[0]) >> 10; v[c + 32] = (x[3] - t[0]) >> 10;
+    }
+    for (int r = 0; r < 8; r++, out += stride) {                        // rows: remove 2^17 with rounding, level-shift by +128
+        int x[4], t[4]; idct8(v + 8 * r, x, t);
+        for (int k = 0; k < 4; k++) x[k] += 65536 + (128 << 17);
+        out[0] = clamp255((x[0] + t[3]) >> 17); out[7] = clamp255((x[0] - t[3]) >> 17);
+        out[1] = clamp255((x[1] + t[2]) >> 17); out[6] = clamp255((x[1] - t[2]) >> 17);
+        out[2] = clamp255((x[2] + t[1]) >> 17); out[5] = clamp255((x[2] - t[1]) >> 17);
+        out[3] = clamp255((x[3] + t[0]) >> 17); out[4] = clamp255((x[3] - t[0]) >> 17);
+    }
+}
+
+// one output row of a component from its low-resolution rows `nr` (nearer) and `fr` (farther); w = low-resolution width
+const uint8_t* jpegUpsampleRow(uint8_t* out, const uint8_t* nr, const uint8_t* fr, int w, int hs, int vs)
+{
+    if (hs == 1 && vs == 1) return nr;
+    if (hs == 1 && vs == 2) { for (int i = 0; i < w; i++) out[i] = (uint8_t)((3 * nr[i] + fr[i] + 2) >> 2); return out; }
+    if (hs == 2 && vs == 1) {
+        if (w == 1) { out[0] = out[1] = nr[0]; return out; }
+        out[0] = nr[0]; out[1] = (uint8_t)((nr[0] * 3 + nr[1] + 2) >> 2);
+        int i = 1;
+        for (; i < w - 1; i++) { const int n = 3 * nr[i] + 2; out[2 * i] = (uint8_t)((n + nr[i - 1]) >> 2); out[2 * i + 1] = (uint8_t)((n + nr[i + 1]) >> 2); }
+        out[2 * i] = (uint8_t)((nr[w - 2] * 3 + nr[w - 1] + 2) >> 2); out[2 * i + 1] = nr[w - 1];
+        return out;
+    }
+    if (hs == 2 && vs == 2) {
+        if (w == 1) { out[0] = out[1] = (uint8_t)((3 * nr[0] + fr[0] + 2) >> 2); return out; }
+        int t1 = 3 * nr[0] + fr[0];
+        out[0] = (uint8_t)((t1 + 2) >> 2);
+        for (int i = 1; i < w; i++) {
+            const int t0 = t1; t1 = 3 * nr[i] + fr[i];
+            out[2 * i - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4); out[2 * i] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
+        }
+        out[2 * w - 1] = (uint8_t)((t1 + 2) >> 2);
+        return out;
+    }
+    for (int i = 0; i < w; i++) for (int j = 0; j < hs; j++) out[i * hs + j] = nr[i];       // nearest
+    return out;
+}
+
+Raw decodeJpeg(const std::string& d, const std::string& path)
+{
+    const uint8_t* p = (const uint8_t*)d.data(); const size_t size = d.size();
+    uint16_t quant[4][64]; bool haveQ[4] = {false, false, false, false};
+    JpegHuff hdc[4], hac[4];
+    std::vector<JpegComp> comp; int W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, adobe = -1; bool jfif = false, haveFrame = false, decoded = false;
+    size_t o = 2;
+    auto need = [&](size_t n) { if (o + n > size) fail(path + ": truncated JPEG"); };
+    for (;;) {
+        need(2);
+        if (p[o] != 0xFF) fail(path + ": corrupt JPEG (marker expected)");
+        while (o < size && p[o] == 0xFF) o++;                           // fill bytes before a marker
+        need(1);
+        const int m = p[o++];
+        if (m == 0xD9) break;                                           // EOI
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;            // standalone markers
+        need(2);
+        const size_t L = ((size_t)p[o] << 8) | p[o + 1];
+        if (L < 2) fail(path + ": corrupt JPEG (segment length)");
+        need(L);
+        const uint8_t* q = p + o + 2; const size_t n = L - 2;
+        if (m == 0xDB) {                                                // DQT
+            size_t i = 0;
+            while (i < n) {
+                const int pq = q[i] >> 4, t = q[i] & 15; i++;
+                if (t > 3 || pq > 1 || i + (size_t)64 * (pq + 1) > n) fail(path + ": corrupt JPEG (DQT)");
+                for (int k = 0; k < 64; k++) { quant[t][kZigzag[k]] = pq ? (uint16_t)((q[i] << 8) | q[i + 1]) : q[i]; i += pq + 1; }
+                haveQ[t] = true;
+            }
+        } else if (m == 0xC4) {                                         // DHT
+            size_t i = 0;
+            while (i < n) {
+                if (i + 17 > n) fail(path + ": corrupt JPEG (DHT)");
+                const int tc = q[i] >> 4, th = q[i] & 15; i++;
+                if (tc > 1 || th > 3) fail(path + ": corrupt JPEG (DHT)");
+                JpegHuff& h = tc ? hac[th] : hdc[th];
+                int total = 0; for (int l = 1; l <= 16; l++) { h.bits[l] = q[i++]; total += h.bits[l]; }
+                if (total > 256 || i + (size_t)total > n) fail(path + ": corrupt JPEG (DHT)");
+                for (int k = 0; k < total; k++) h.vals[k] = q[i++];
+                jpegBuildHuff(h, path);
+            }
+        } else if (m == 0xDD) { if (n < 2) fail(path + ": corrupt JPEG (DRI)"); restart = (q[0] << 8) | q[1]; }
+        else if (m == 0xE0) { if (n >= 5 && memcmp(q, "JFIF\0", 5) == 0) jfif = true; }
+        else if (m == 0xEE) { if (n >= 12 && memcmp(q, "Adobe\0", 6) == 0) adobe = q[11]; }
+        else if (m == 0xC0 || m == 0xC1) {                              // SOF0 / SOF1
+            if (haveFrame) fail(path + ": corrupt JPEG (two frame headers)");
+            if (n < 6 || q[0] != 8) fail(path + ": only 8-bit JPEG is supported");
+            H = (q[1] << 8) | q[2]; W = (q[3] << 8) | q[4];
+            const int nc = q[5];
+            if (W == 0 || H == 0) fail(path + ": JPEG with zero size / DNL height is not supported");
+            if (nc != 1 && nc != 3) fail(path + ": only 1- and 3-component JPEG is supported (no CMYK / YCCK)");
+            if (n < (size_t)6 + 3 * nc) fail(path + ": corrupt JPEG (SOF)");
+            comp.resize(nc);
+            for (int k = 0; k < nc; k++) {
+                comp[k].id = q[6 + 3 * k]; comp[k].h = q[7 + 3 * k] >> 4; comp[k].v = q[7 + 3 * k] & 15; comp[k].tq = q[8 + 3 * k];
+                if (comp[k].h < 1 || comp[k].h > 4 || comp[k].v < 1 || comp[k].v > 4 || comp[k].tq > 3) fail(path + ": corrupt JPEG (sampling factors)");
+                if (comp[k].h > hmax) hmax = comp[k].h;
+                if (comp[k].v > vmax) vmax = comp[k].v;
+            }
+            for (auto& c : comp) if (hmax % c.h || vmax % c.v) fail(path + ": corrupt JPEG (sampling factors)");
+            const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+            for (auto& c : comp) {
+                c.x = (W * c.h + hmax - 1) / hmax; c.y = (H * c.v + vmax - 1) / vmax;            // samples that carry image data
+                c.w2 = mcux * c.h * 8; c.h2 = mcuy * c.v * 8;                                    // padded to whole MCUs
+                c.plane.assign((size_t)c.w2 * c.h2 + 15, 0);
+            }
+            haveFrame = true;
+        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+            fail(path + ": progressive / lossless / arithmetic-coded JPEG is not supported (baseline only)");
+        } else if (m == 0xDA) {                                         // SOS + entropy-coded data
+            if (!haveFrame) fail(path + ": corrupt JPEG (scan before frame)");
+            if (n < 1) fail(path + ": corrupt JPEG (SOS)");
+            const int ns = q[0];
+            if (ns < 1 || ns > (int)comp.size() || n < (size_t)1 + 2 * ns + 3) fail(path + ": corrupt JPEG (SOS)");
+            int order[4];
+            for (int k = 0; k < ns; k++) {
+                int ci = -1; for (size_t c = 0; c < comp.size(); c++) if (comp[c].id == q[1 + 2 * k]) ci = (int)c;
+                if (ci < 0) fail(path + ": corrupt JPEG (scan component)");
+                comp[ci].td = q[2 + 2 * k] >> 4; comp[ci].ta = q[2 + 2 * k] & 15;
+                if (comp[ci].td > 3 || comp[ci].ta > 3 || !hdc[comp[ci].td].present || !hac[comp[ci].ta].present || !haveQ[comp[ci].tq]) fail(path + ": corrupt JPEG (missing table)");
+                order[k] = ci;
+            }
+            JpegBits b{p, size, o + L};
+            for (auto& c : comp) c.pred = 0;
+            int todo = restart ? restart : 0x7fffffff;
+            short blk[64];
+            auto block = [&](JpegComp& c, int bx, int by) {
+                memset(blk, 0, sizeof(blk));
+                const int t = jpegDecodeSym(b, hdc[c.td], path);
+                if (t > 15) fail(path + ": corrupt JPEG (DC size)");
+                c.pred += jpegExtend(b.receive(t), t);
+                blk[0] = (short)(c.pred * quant[c.tq][0]);
+                for (int k = 1; k < 64;) {
+                    const int rs = jpegDecodeSym(b, hac[c.ta], path), r = rs >> 4, sz = rs & 15;
+                    if (sz == 0) { if (rs != 0xF0) break; k += 16; continue; }
+                    k += r;
+                    if (k > 63) fail(path + ": corrupt JPEG (AC run)");
+                    const int z = kZigzag[k++];
+                    blk[z] = (short)(jpegExtend(b.receive(sz), sz) * quant[c.tq][z]);
+                }
+                jpegIdct(&c.plane[(size_t)c.w2 * by * 8 + (size_t)bx * 8], c.w2, blk);
+            };
+            auto mcuDone = [&]() -> bool {                              // false: the segment ended without the expected restart marker
+                if (--todo > 0) return true;
+                if (b.cnt < 24) b.fill();
+                if (!(b.marker >= 0xD0 && b.marker <= 0xD7)) return false;
+                b.reset(); for (auto& c : comp) c.pred = 0; todo = restart ? restart : 0x7fffffff;
+                return true;
+            };
+            if (ns == 1) {                                              // non-interleaved: the component's own blocks in raster order
+                JpegComp& c = comp[order[0]];
+                const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3; bool go = true;
+                for (int j = 0; j < bh && go; j++) for (int i = 0; i < bw && go; i++) { block(c, i, j); go = mcuDone(); }
+            } else {
+                const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax); bool go = true;
+                for (int j = 0; j < mcuy && go; j++) for (int i = 0; i < mcux && go; i++) {
+                    for (int k = 0; k < ns; k++) { JpegComp& c = comp[order[k]]; for (int y = 0; y < c.v; y++) for (int x = 0; x < c.h; x++) block(c, i * c.h + x, j * c.v + y); }
+                    go = mcuDone();
+                }
+            }
+            decoded = true;
+            // continue behind the entropy-coded segment: at the marker that ended it, or search for the next one
+            size_t e = b.pos;
+            if (b.marker) { o = e - 2; while (o > 0 && !(p[o] == 0xFF && p[o + 1] == (uint8_t)b.marker)) o--; continue; }
+            while (e + 1 < size && !(p[e] == 0xFF && p[e + 1] != 0 && p[e + 1] != 0xFF && !(p[e + 1] >= 0xD0 && p[e + 1] <= 0xD7))) e++;
+            if (e + 1 >= size) break;
+            o = e; continue;
+        }
+        o += L;
+    }
+    if (!haveFrame || !decoded) fail(path + ": JPEG without image data");
+    const int nc = (int)comp.size();
+    int rgbIds = 0; if (nc == 3) { const char* tag = "RGB"; for (int k = 0; k < 3; k++) if (comp[k].id == tag[k]) rgbIds++; }
+    const bool isRgb = nc == 3 && (rgbIds == 3 || (adobe == 0 && !jfif));
+    Raw r; r.w = W; r.h = H; r.n = nc == 3 ? 3 : 1; r.px.resize((size_t)W * H * r.n);
+    struct Walk { int hs, vs, ystep, wl, ypos; const uint8_t *l0, *l1; std::vector<uint8_t> buf; };
+    std::vector<Walk> wk(nc);
+    for (int k = 0; k < nc; k++) {
+        Walk& w = wk[k]; w.hs = hmax / comp[k].h; w.vs = vmax / comp[k].v; w.ystep = w.vs >> 1; w.wl = (W + w.hs - 1) / w.hs; w.ypos = 0;
+        w.l0 = w.l1 = comp[k].plane.data(); w.buf.resize((size_t)W + 8);
+    }
+    const uint8_t* row[3] = {nullptr, nullptr, nullptr};
+    for (int j = 0; j < H; j++) {
+        for (int k = 0; k < nc; k++) {
+            Walk& w = wk[k];
+            const bool bot = w.ystep >= (w.vs >> 1);
+            row[k] = jpegUpsampleRow(w.buf.data(), bot ? w.l1 : w.l0, bot ? w.l0 : w.l1, w.wl, w.hs, w.vs);
+            if (++w.ystep >= w.vs) { w.ystep = 0; w.l0 = w.l1; if (++w.ypos < comp[k].y) w.l1 += comp[k].w2; }
+        }
+        uint8_t* out = &r.px[(size_t)j * W * r.n];
+        if (nc == 1) memcpy(out, row[0], (size_t)W);
+        else if (isRgb) for (int i = 0; i < W; i++) { out[3 * i] = row[0][i]; out[3 * i + 1] = row[1][i]; out[3 * i + 2] = row[2][i]; }
+        else for (int i = 0; i < W; i++) {
+            const int yf = (row[0][i] << 20) + (1 << 19), cb = row[1][i] - 128, cr = row[2][i] - 128;
+            // fixed-point factors: round(c * 4096) << 8
+            int rr = yf + cr * (5743 << 8);
+            int gg = yf + cr * -(2925 << 8) + (int)((uint32_t)(cb * -(1410 << 8)) & 0xffff0000u);
+            int bb = yf + cb * (7258 << 8);
+            out[3 * i] = clamp255(rr >> 20); out[3 * i + 1] = clamp255(gg >> 20); out[3 * i + 2] = clamp255(bb >> 20);
+        }
+    }
+    return r;
+}
+
 Raw decodePnm(const std::string& d, const std::string& path)
 {
     size_t o = 2; int vals[3], got = 0;
@@ -355,7 +659,7 @@ Image LoadImage(const std::string& path)
     Raw r;
     if (d.size() >= 8 && memcmp(d.data(), "\x89PNG\r\n\x1a\n", 8) == 0) r = decodePng(d, path);
     else if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) r = decodePnm(d, path);
-    else if (d.size() >= 3 && (uint8_t)d[0] == 0xFF && (uint8_t)d[1] == 0xD8) fail(path + ": JPEG textures are not supported by this loader yet (convert to PNG)");
+    else if (d.size() >= 3 && (uint8_t)d[0] == 0xFF && (uint8_t)d[1] == 0xD8) r = decodeJpeg(d, path);
     else r = decodeTga(d, path);
     Image img; img.width = r.w; img.height = r.h; img.pixels.resize((size_t)r.w * r.h);
     const size_t s = (size_t)r.w * r.h;

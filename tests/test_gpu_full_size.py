@@ -145,6 +145,14 @@ def test_config4_tower_1080p_256spp(crt, orc):
     c1.render(1, S, 1)
     assert np.array_equal(c1.accumulator(), acc) and c1.timing()["render_launches"] == 4
     c1.close()
+    # the same scene file naming the reference's own Wood_Tower_Col.jpg (host loader's JPEG reader = stb_image's texels)
+    hj = crt.HostScene(scene_path("tower_scene_jpg.xml"), 0, ASSETS)
+    c2 = crt.Context(Wt, Ht)
+    hj.upload(c2)
+    c2.render(1, 64, 1)
+    ctx.clear(); ctx.render(1, 64, 1)
+    assert np.array_equal(c2.accumulator(), ctx.accumulator())
+    c2.close()
     assert np.isfinite(acc).all() and not acc[1072:].any() and acc[:1072, :, :3].any()
     o, _ = orc.load_scene(scene_path("tower_scene.xml"), 0, ASSETS)
     o.renderer_init(Wt, Ht)

@@ -61,6 +61,33 @@ def test_loaders_match_independent_readers(crt, orc):
         assert np.array_equal(crt.load_image(p), orc.pack_rgb(orc.read_image(p))), f
 
 
+def test_jpeg_loader_matches_stb_golden(crt):
+    """Baseline JPEG in the host loader: texels must be the ones the reference's stbi_load produces (template/texture.h:18).
+    tests/golden/jpeg/*.jpg were decoded by the REAL lib/stb_image.h (oracle/_ref) when the fixtures were made
+    (tests/golden/make_jpeg_golden.py): 4:4:4 / 4:2:2 / 4:2:0, greyscale, odd sizes down to 1x1, restart intervals, optimised
+    Huffman tables, and the reference's own Wood_Tower_Col.jpg (BASELINE config 4's texture)."""
+    import json, zlib
+    G = json.load(open(os.path.join(REPO, "tests", "golden", "jpeg_golden.json")))
+    for name, g in sorted(G.items()):
+        path = os.path.join(ASSETS, "textures", name + ".jpg") if name == "Wood_Tower_Col" else os.path.join(REPO, "tests", "golden", "jpeg", name + ".jpg")
+        a = crt.load_image(path)
+        assert list(a.shape) == g["shape"][:2], name
+        assert (zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff) == g["packed"], name
+    # the stb-decoded PNG fixture of the same texture (tools/make_tower_texture.py) holds the same texels
+    assert np.array_equal(crt.load_image(os.path.join(ASSETS, "textures", "Wood_Tower_Col.jpg")), crt.load_image(os.path.join(ASSETS, "textures", "Wood_Tower_Col.png")))
+    with pytest.raises(crt.CrtError) as e:
+        crt.load_image(os.path.join(REPO, "tests", "golden", "jpeg", "progressive_32x32.jpg"))
+    assert "progressive" in str(e.value) and e.value.code == -6
+    bad = open(os.path.join(REPO, "tests", "golden", "jpeg", "rgb420_16x16_q50.jpg"), "rb").read()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for cut in (3, 100, len(bad) // 2):
+            p = os.path.join(d, "cut%d.jpg" % cut)
+            open(p, "wb").write(bad[:cut])
+            with pytest.raises(crt.CrtError):
+                crt.load_image(p)
+
+
 def test_obj_edge_cases(crt, orc, tmp_path):
     """ragged input: relative indices, missing vt/vn, quads on either diagonal, a pentagon, blank lines, CRLF, exponents."""
     text = "\r\n".join([

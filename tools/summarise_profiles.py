@@ -49,6 +49,7 @@ if rk and "FETCH_SIZE" in pmc[rk[0]] and "WRITE_SIZE" in pmc[rk[0]]:
     ak = [k for k in pmc if "accumulate_kernel" in k]
     if ak and "FETCH_SIZE" in pmc[ak[0]]:
         out["accumulate_kernel_fetch_bytes_x2"] = int(2 * pmc[ak[0]]["FETCH_SIZE"]["max_dispatch"] * 1024)   # wide coalesced streaming reads: the guide's x2 correction applies
+    out["workload"] = ["bunny_scene.xml", 0, 1280, 720, 64, 64]      # bench.py defaults: scene, kind, W, H, spp per step, steps per job (ONE launch)
     json.dump(out, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     print(out)
 print("profiles written for", tag)
