@@ -56,7 +56,7 @@ ABI_SYMBOLS = ["crt_abi_version", "crt_device_count", "crt_create", "crt_destroy
                "crt_reset_counters", "crt_get_timing", "crt_get_tile_clocks", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
 HOST_SYMBOLS = ["crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
                 "crt_host_scene_triangle_count", "crt_host_scene_bvh_count", "crt_host_scene_bvh_info", "crt_host_scene_bvh_copy",
-                "crt_host_scene_blas_transform", "crt_host_scene_tlas_copy", "crt_host_camera_state", "crt_host_renderer_create",
+                "crt_host_scene_bvh_move_and_refit", "crt_host_scene_blas_transform", "crt_host_scene_tlas_copy", "crt_host_camera_state", "crt_host_renderer_create",
                 "crt_host_renderer_destroy", "crt_host_renderer_init", "crt_host_renderer_set_camera", "crt_host_renderer_set_passes",
                 "crt_host_renderer_clear", "crt_host_renderer_tick", "crt_host_renderer_render", "crt_host_renderer_tick_whitted", "crt_host_renderer_spp",
                 "crt_host_renderer_energy", "crt_host_renderer_accumulator", "crt_host_renderer_screen", "crt_host_renderer_ctx",
@@ -270,6 +270,11 @@ class HostScene:
         tris = np.zeros(tc.value, TRI_DTYPE)
         self._ck(self.L.crt_host_scene_bvh_copy(self.h, i, _p(nodes), _p(idx), _p(tris)))
         return dict(nodes=nodes, triIndices=idx, tris=tris, nodesUsed=nu.value, maxDepth=md.value)
+
+    def move_and_refit(self, i, positions):
+        """BVH::Refit for moved vertices: positions = (triCount, 3, 3) floats in the reference's triangle order; upload() again afterwards"""
+        positions = np.ascontiguousarray(positions, np.float32)
+        self._ck(self.L.crt_host_scene_bvh_move_and_refit(self.h, int(i), _p(positions), C.c_uint32(positions.shape[0])))
 
     def blas_transform(self, i):
         T, invT, lo, hi = np.zeros(16, np.float32), np.zeros(16, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)

@@ -125,6 +125,26 @@ void Dedup(const MeshCorners& m, std::vector<float>& P, std::vector<float>& N, s
 
 } // namespace
 
+void RefitSAH(const std::vector<Tri>& tris, std::vector<BVHNode>& nodes, const std::vector<uint32_t>& idx, uint32_t nodesUsed)
+{
+    for (int i = (int)nodesUsed - 1; i >= 0; i--) {
+        if (i == 1) continue;                                              // bvh.cpp:28
+        BVHNode& node = nodes[(size_t)i];
+        if (node.triCount > 0) {                                           // leaf: tight bounds of its triangles (UpdateNodeBounds)
+            float3 lo(1e30f), hi(-1e30f);
+            for (uint32_t k = 0; k < node.triCount; k++) {
+                const Tri& t = tris[idx[node.leftFirst + k]];
+                lo = fminf3(lo, V(t.vertex0)); lo = fminf3(lo, V(t.vertex1)); lo = fminf3(lo, V(t.vertex2));
+                hi = fmaxf3(hi, V(t.vertex0)); hi = fmaxf3(hi, V(t.vertex1)); hi = fmaxf3(hi, V(t.vertex2));
+            }
+            S(node.aabbMin, lo); S(node.aabbMax, hi);
+        } else {                                                           // interior: union of the two children
+            const BVHNode& l = nodes[node.leftFirst]; const BVHNode& r = nodes[node.leftFirst + 1];
+            S(node.aabbMin, fminf3(V(l.aabbMin), V(r.aabbMin))); S(node.aabbMax, fmaxf3(V(l.aabbMax), V(r.aabbMax)));
+        }
+    }
+}
+
 void BuildSAH(std::vector<Tri>& triangles, std::vector<BVHNode>& nodes, std::vector<uint32_t>& triangleIndices, uint32_t& nodesUsed, uint32_t& maxDepth)
 {
     if (triangles.empty()) throw std::runtime_error("BVH::Build: no triangles");

@@ -23,10 +23,15 @@ struct MeshCorners {           // tinyobj-resolved corners, three per triangle (
 
 // binned-SAH builder shared by BVH and BLASBVH (the reference duplicates the code: bvh.cpp:4-178, blas_bvh.cpp:82-256)
 void BuildSAH(std::vector<Tri>& triangles, std::vector<BVHNode>& nodes, std::vector<uint32_t>& triangleIndices, uint32_t& nodesUsed, uint32_t& maxDepth);
+// BVH::Refit / BLASBVH::Refit (bvh.cpp:26-43, blas_bvh.cpp:104-121): bounds of every node recomputed bottom-up for moved vertices,
+// topology unchanged.  Node 1 is skipped exactly as the reference does (its loop tests `i != 1`, a left-over of the tutorial layout
+// that keeps node 1 unused; here node 1 is the root's left child, so its box stays as built — bug-compatible).
+void RefitSAH(const std::vector<Tri>& triangles, std::vector<BVHNode>& nodes, const std::vector<uint32_t>& triangleIndices, uint32_t nodesUsed);
 
 class BVH {
 public:
     void Build() { BuildSAH(triangles, bvhNodes, triangleIndices, nodesUsed, maxDepth); }
+    void Refit() { RefitSAH(triangles, bvhNodes, triangleIndices, nodesUsed); }
     int GetTriangleCount() const { return (int)triangles.size(); }
     int objIdx = -1;
     std::vector<BVHNode> bvhNodes;
@@ -42,6 +47,7 @@ public:
     // infra/blas_bvh.cpp:4-80: de-duplicated vertices -> triangles with the scale baked in, Build(), SetTransform(T)
     BLASBVH(int idx, const MeshCorners& mesh, const mat4& transform, const mat4& scaleMat);
     void Build() { BuildSAH(triangles, bvhNodes, triangleIndices, nodesUsed, maxDepth); }
+    void Refit() { RefitSAH(triangles, bvhNodes, triangleIndices, nodesUsed); }
     void SetTransform(const mat4& transform);
     int GetTriangleCount() const { return (int)triangles.size(); }
     int objIdx = -1, matIdx = -1;

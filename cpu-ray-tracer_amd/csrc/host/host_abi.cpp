@@ -73,6 +73,24 @@ int crt_host_scene_bvh_copy(crt_host_scene* s, int i, crt_bvh_node* nodes, uint3
     if (tris) memcpy(tris, t->data(), sizeof(Tri) * t->size());
     return CRT_OK;
 }
+int crt_host_scene_bvh_move_and_refit(crt_host_scene* s, int i, const float* positions, uint32_t triCount)
+{
+    if (!s || !positions) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    GUARD_BEGIN
+    std::vector<Tri>* tris = nullptr;
+    BLASBVH* blas = nullptr;
+    if (s->file) { if (i != 0) { g_err = "bvh index out of range"; return CRT_ERR_INVALID; } tris = &s->file->acc.triangles; }
+    else { if (i < 0 || i >= (int)s->tlas->tlas.blas.size()) { g_err = "bvh index out of range"; return CRT_ERR_INVALID; } blas = s->tlas->tlas.blas[(size_t)i]; tris = &blas->triangles; }
+    if (triCount != tris->size()) { g_err = "triangle count does not match the built BVH (Refit keeps the topology)"; return CRT_ERR_INVALID; }
+    for (uint32_t t = 0; t < triCount; t++) {
+        memcpy((*tris)[t].vertex0, positions + 9 * (size_t)t, 12); memcpy((*tris)[t].vertex1, positions + 9 * (size_t)t + 3, 12);
+        memcpy((*tris)[t].vertex2, positions + 9 * (size_t)t + 6, 12);
+    }
+    if (s->file) s->file->acc.Refit();
+    else { blas->Refit(); blas->SetTransform(blas->T); s->tlas->tlas.Build(); }      // world bounds + TLAS follow the refitted BLAS, as a per-frame animation loop does
+    return CRT_OK;
+    GUARD_END(CRT_ERR_INVALID)
+}
 int crt_host_scene_blas_transform(crt_host_scene* s, int i, float T[16], float invT[16], float lo[3], float hi[3])
 {
     if (!s || !s->tlas || i < 0 || i >= (int)s->tlas->tlas.blas.size()) { g_err = "not a TLAS scene / index out of range"; return CRT_ERR_INVALID; }

@@ -36,6 +36,11 @@ int  crt_host_scene_triangle_count(crt_host_scene* scene);
 int  crt_host_scene_bvh_count(crt_host_scene* scene);
 int  crt_host_scene_bvh_info(crt_host_scene* scene, int bvh, uint32_t* nodesUsed, uint32_t* triCount, uint32_t* maxDepth);
 int  crt_host_scene_bvh_copy(crt_host_scene* scene, int bvh, crt_bvh_node* nodes, uint32_t* triangleIndices, crt_tri* triangles);
+/* BVH::Refit / BLASBVH::Refit (infra/bvh.cpp:26-43, blas_bvh.cpp:104-121) for moved vertices: replaces the vertex positions of BVH `bvh`
+ * (9 floats per triangle, reference triangle order; the topology stays), refits its node bounds on the CPU and, for a TLAS scene,
+ * re-derives the instance's world bounds (SetTransform, blas_bvh.cpp:363-374) and rebuilds the TLAS (tlas_bvh.cpp:17-70).  Call
+ * crt_host_scene_upload again afterwards: the device layout is re-flattened from the refitted arrays. */
+int  crt_host_scene_bvh_move_and_refit(crt_host_scene* scene, int bvh, const float* positions, uint32_t triCount);
 int  crt_host_scene_blas_transform(crt_host_scene* scene, int bvh, float T[16], float invT[16], float worldMin[3], float worldMax[3]);
 int  crt_host_scene_tlas_copy(crt_host_scene* scene, crt_tlas_node* nodes /* 2*blasCount */, uint32_t* nodesUsed);
 

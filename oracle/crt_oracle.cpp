@@ -298,6 +298,16 @@ struct Bvh {
         }
         st3(n.aabbMin, lo); st3(n.aabbMax, hi);
     }
+    void refit() // bvh.cpp:26-43 (blas_bvh.cpp:104-121): bottom-up, node 1 skipped as the reference's loop does
+    {
+        for (int i = (int)nodesUsed - 1; i >= 0; i--) if (i != 1) {
+            Node& n = nodes[(size_t)i];
+            if (n.triCount > 0) { update_bounds((uint)i); continue; }
+            const Node& l = nodes[n.leftFirst]; const Node& r = nodes[n.leftFirst + 1];
+            st3(n.aabbMin, vmin(ld3(l.aabbMin), ld3(r.aabbMin)));
+            st3(n.aabbMax, vmax(ld3(l.aabbMax), ld3(r.aabbMax)));
+        }
+    }
     float node_cost(const Node& n) // bvh.cpp:117-122
     {
         float ex = n.aabbMax[0] - n.aabbMin[0], ey = n.aabbMax[1] - n.aabbMin[1], ez = n.aabbMax[2] - n.aabbMin[2];
@@ -944,6 +954,22 @@ int orc_bvh_copy(orc_ctx* c, int i, orc_bvh_node* nodes, uint32_t* triIndices, o
     if (nodes) memcpy(nodes, b->nodes.data(), sizeof(Node) * b->nodesUsed);
     if (triIndices) memcpy(triIndices, b->triIdx.data(), 4 * b->triIdx.size());
     if (tris) memcpy(tris, b->tris.data(), sizeof(Tri) * b->tris.size());
+    return 0;
+}
+// moved vertices + Refit (the reference's animation hook; "next" row of SURVEY 8(f)): replaces the vertex positions of BVH i
+// (3 x 3 floats per triangle, reference triangle order), refits it, and for a TLAS scene re-derives the instance's world bounds
+// (SetTransform, blas_bvh.cpp:363-374) and rebuilds the TLAS (tlas_bvh.cpp:17-70) as a per-frame animation loop would
+int orc_bvh_move_and_refit(orc_ctx* c, int i, const float* positions, uint32_t triCount)
+{
+    if (!c->built || i < 0 || i >= (int)c->bvhs.size()) return -1;
+    Bvh* b = c->bvhs[i];
+    if (triCount != b->tris.size()) return -1;
+    for (uint32_t t = 0; t < triCount; t++) {
+        memcpy(b->tris[t].vertex0, positions + 9 * (size_t)t, 12); memcpy(b->tris[t].vertex1, positions + 9 * (size_t)t + 3, 12);
+        memcpy(b->tris[t].vertex2, positions + 9 * (size_t)t + 6, 12);
+    }
+    b->refit();
+    if (c->kind == 1) { b->set_transform(b->T); if (!c->tlas.build(c->err)) return -1; }
     return 0;
 }
 int orc_blas_transform(orc_ctx* c, int i, float T[16], float invT[16], float lo[3], float hi[3])

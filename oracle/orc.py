@@ -169,6 +169,10 @@ class Oracle:
         self._ck(self.L.orc_blas_transform(self.h, i, _fp(T), _fp(invT), _fp(lo), _fp(hi)))
         return T, invT, lo, hi
 
+    def move_and_refit(self, i, positions):
+        positions = np.ascontiguousarray(positions, np.float32)
+        self._ck(self.L.orc_bvh_move_and_refit(self.h, i, _fp(positions), C.c_uint32(positions.shape[0])))
+
     def tlas(self):
         n = self.bvh_count()
         nodes = np.zeros(2 * n, TLAS_DTYPE)
@@ -563,6 +567,17 @@ class Ref:
         idx = np.zeros(len(tris), np.uint32)
         self.L.ref_bvh_copy(h, _fp(nodes), _fp(idx))
         return h, dict(nodes=nodes, triIndices=idx, nodesUsed=nu.value, maxDepth=md.value)
+
+    def bvh_move_and_refit(self, h, positions):
+        """the reference's BVH::Refit after replacing the vertex positions ((n, 3, 3) floats); returns the node array"""
+        positions = np.ascontiguousarray(positions, np.float32)
+        self.L.ref_bvh_move_and_refit(h, _fp(positions), C.c_uint32(positions.shape[0]))
+        nu, md = C.c_uint32(), C.c_uint32()
+        self.L.ref_bvh_info(h, C.byref(nu), C.byref(md))
+        nodes = np.zeros(nu.value, NODE_DTYPE)
+        idx = np.zeros(positions.shape[0], np.uint32)
+        self.L.ref_bvh_copy(h, _fp(nodes), _fp(idx))
+        return nodes
 
     def bvh_intersect(self, h, O, D):
         O = np.ascontiguousarray(O, np.float32).reshape(-1, 3)

@@ -2,7 +2,7 @@
  * ref_harness.cpp — C entry points around the REAL reference code, compiled where it lies (oracle/_ref only;
  * never shipped, never loaded by the product).  Everything below the includes is glue: it fills the reference's
  * own containers, calls the reference's own functions and copies their results out.
- *   infra/bvh.cpp            -> BVH::Build, BVH::Intersect (IntersectBVH / IntersectAABB / IntersectTri)
+ *   infra/bvh.cpp            -> BVH::Build, BVH::Refit, BVH::Intersect (IntersectBVH / IntersectAABB / IntersectTri)
  *   lib/tiny_obj_loader.h    -> tinyobj::LoadObj (float parsing, quad / polygon triangulation)
  *   lib/stb_image.h          -> stbi_load (PNG / JPG / TGA decode)
  */
@@ -41,6 +41,18 @@ void ref_bvh_copy(void* h, void* nodes32, uint32_t* triIdx)
     BVH* b = (BVH*)h;
     memcpy(nodes32, b->bvhNodes.data(), (size_t)b->nodesUsed * sizeof(BVHNode));
     memcpy(triIdx, b->triangleIndices.data(), b->triangleIndices.size() * 4);
+}
+/* BVH::Refit of the reference (infra/bvh.cpp:26-43) after moving the vertices: positions = 9 floats per triangle */
+void ref_bvh_move_and_refit(void* h, const float* positions, uint32_t n)
+{
+    BVH* b = (BVH*)h;
+    for (uint32_t i = 0; i < n && i < b->triangles.size(); i++) {
+        Tri& t = b->triangles[i];
+        t.vertex0 = float3(positions[9 * i], positions[9 * i + 1], positions[9 * i + 2]);
+        t.vertex1 = float3(positions[9 * i + 3], positions[9 * i + 4], positions[9 * i + 5]);
+        t.vertex2 = float3(positions[9 * i + 6], positions[9 * i + 7], positions[9 * i + 8]);
+    }
+    b->Refit();
 }
 void ref_bvh_intersect(void* h, const float* O, const float* D, uint32_t n, ref_hit* out)
 {

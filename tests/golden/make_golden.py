@@ -40,6 +40,12 @@ def simple_scene(mesh, kind=0, pos=(0, -1, 2), rot=(0, 180, 0), scale=(1, 1, 1))
     return o
 
 
+def deform(p):
+    """vertex animation stand-in: p + 0.1 * (p.yzx * p.zxy), float32 products and sums only (bit-reproducible everywhere)"""
+    p = np.asarray(p, np.float32)
+    return (p + np.float32(0.1) * (p[..., [1, 2, 0]] * p[..., [2, 0, 1]])).astype(np.float32)
+
+
 def main():
     orc.build()
     ref = orc.Ref()
@@ -74,6 +80,10 @@ def main():
             hits = ref.bvh_intersect(h, O, D)
             rays[m] = dict(O=O, D=D, t=hits["t"], u=hits["u"], v=hits["v"], objIdx=hits["objIdx"], triIdx=hits["triIdx"],
                            traversed=hits["traversed"], tested=hits["tested"])
+        if m in ("bunny", "cube", "teapot"):
+            # --- ref_refit: the reference's BVH::Refit (bvh.cpp:26-43) after a deterministic deformation of the vertices ---------
+            moved = deform(np.stack([tris["vertex0"], tris["vertex1"], tris["vertex2"]], axis=1))
+            out.setdefault("ref_refit", {})[m] = dict(nodes=crc(ref.bvh_move_and_refit(h, moved)), moved=crc(moved))
         ref.bvh_free(h)
     np.savez_compressed(os.path.join(HERE, "ref_bvh_rays.npz"), **{"%s_%s" % (m, k): v for m, d in rays.items() for k, v in d.items()})
     # --- orc_render: oracle accumulators of the BASELINE scenes at small sizes (regression vectors) ------------------

@@ -98,3 +98,33 @@ def test_general_code_paths_are_bit_identical(crt, monkeypatch, switch, xml, kin
     monkeypatch.delenv(switch)
     assert np.array_equal(out[0][0], out[1][0])
     assert out[0][1] == out[1][1]
+
+
+@pytest.mark.parametrize("xml,kind", [("bunny_scene.xml", 0), ("tlas_scene.xml", 1)])
+def test_render_after_refit_matches_oracle(crt, orc, xml, kind):
+    """moved vertices -> Refit on the CPU (host front) -> crt_host_scene_upload again -> the HIP path renders the refitted scene
+    exactly as the oracle does (the oracle's Refit is pinned to the real reference's, tests/golden ref_refit)"""
+    from test_oracle_pinning import deform
+    W, H, frames = 128, 96, 2
+    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    o, _ = orc.load_scene(scene_path(xml), kind, ASSETS)
+    ctx = crt.Context(W, H, collect_stats=True)
+    hs.upload(ctx)
+    ctx.render(1, frames, 1)
+    before = ctx.accumulator()
+    i = hs.bvh_count() - 1
+    t = hs.bvh(i)["tris"]
+    moved = deform(np.stack([t["vertex0"], t["vertex1"], t["vertex2"]], axis=1))
+    hs.move_and_refit(i, moved)
+    o.move_and_refit(i, moved)
+    hs.upload(ctx)
+    ctx.clear(); ctx.reset_counters()
+    ctx.render(1, frames, 1)
+    acc = ctx.accumulator()
+    o.renderer_init(W, H)
+    o.render(frames, threads=4)
+    assert not np.array_equal(acc, before)
+    assert _eq_pm0(acc, o.accumulator())
+    gc, oc = ctx.counters(), o.counters()
+    for k in gc:
+        assert gc[k] == oc[k], (k, gc[k], oc[k])

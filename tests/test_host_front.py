@@ -61,6 +61,32 @@ def test_loaders_match_independent_readers(crt, orc):
         assert np.array_equal(crt.load_image(p), orc.pack_rgb(orc.read_image(p))), f
 
 
+@pytest.mark.parametrize("xml,kind", [("bunny_scene.xml", 0), ("tlas_scene.xml", 1)])
+def test_refit_matches_oracle(crt, orc, xml, kind):
+    """BVH::Refit / BLASBVH::Refit for moved vertices in the host front (bvh.cpp:26-43): node arrays, and for the two-level scene the
+    instance world bounds + rebuilt TLAS, bit-identical with the oracle's (which is pinned to the real reference's Refit)."""
+    from test_oracle_pinning import deform
+    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    o, _ = orc.load_scene(scene_path(xml), kind, ASSETS)
+    i = hs.bvh_count() - 1
+    t = hs.bvh(i)["tris"]
+    moved = deform(np.stack([t["vertex0"], t["vertex1"], t["vertex2"]], axis=1))
+    before = hs.bvh(i)["nodes"].copy()
+    hs.move_and_refit(i, moved)
+    o.move_and_refit(i, moved)
+    a, b = hs.bvh(i), o.bvh(i)
+    assert not np.array_equal(a["nodes"].view(np.uint8), before.view(np.uint8))
+    assert np.array_equal(a["nodes"].view(np.uint8), b["nodes"].view(np.uint8)) and np.array_equal(a["tris"].view(np.uint8), b["tris"].view(np.uint8))
+    assert np.array_equal(a["triIndices"], b["triIndices"])
+    if kind == 1:
+        for x, y in zip(hs.blas_transform(i), o.blas_transform(i)):
+            assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
+        (na, ua), (nb, ub) = hs.tlas(), o.tlas()
+        assert ua == ub and np.array_equal(na.view(np.uint8), nb.view(np.uint8))
+    with pytest.raises(crt.CrtError):
+        hs.move_and_refit(i, moved[:-1])
+
+
 def test_jpeg_loader_matches_stb_golden(crt):
     """Baseline JPEG in the host loader: texels must be the ones the reference's stbi_load produces (template/texture.h:18).
     tests/golden/jpeg/*.jpg were decoded by the REAL lib/stb_image.h (oracle/_ref) when the fixtures were made

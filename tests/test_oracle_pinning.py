@@ -79,9 +79,43 @@ def test_oracle_traversal_matches_reference_golden(orc, mesh):
     assert np.array_equal(h["tested"][miss], z[mesh + "_tested"][miss])
 
 
+def deform(p):
+    """vertex animation stand-in (same as tests/golden/make_golden.py): p + 0.1 * (p.yzx * p.zxy), float32 products and sums only"""
+    p = np.asarray(p, np.float32)
+    return (p + np.float32(0.1) * (p[..., [1, 2, 0]] * p[..., [2, 0, 1]])).astype(np.float32)
+
+
+@pytest.mark.parametrize("mesh", sorted(G["ref_refit"].keys()))
+def test_oracle_refit_matches_reference_golden(orc, mesh):
+    """BVH::Refit (infra/bvh.cpp:26-43) of the real reference after moving the vertices, incl. its skipped node 1"""
+    o = simple_scene(orc, mesh)
+    t = o.bvh(0)["tris"]
+    moved = deform(np.stack([t["vertex0"], t["vertex1"], t["vertex2"]], axis=1))
+    assert crc(moved) == G["ref_refit"][mesh]["moved"]
+    o.move_and_refit(0, moved)
+    b = o.bvh(0)
+    assert crc(b["nodes"]) == G["ref_refit"][mesh]["nodes"]
+    assert np.array_equal(b["tris"]["vertex1"], moved[:, 1])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # live comparison with the real reference (authoring container)
 # ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mesh", ["bunny", "wok"])
+def test_oracle_refit_vs_reference_live(orc, ref, mesh):
+    o = simple_scene(orc, mesh)
+    t = o.bvh(0)["tris"]
+    h, _ = ref.bvh_build(t)
+    try:
+        moved = deform(np.stack([t["vertex0"], t["vertex1"], t["vertex2"]], axis=1))
+        rn = ref.bvh_move_and_refit(h, moved)
+        o.move_and_refit(0, moved)
+        assert np.array_equal(rn.view(np.uint8), o.bvh(0)["nodes"].view(np.uint8))
+    finally:
+        ref.bvh_free(h)
+
+
+
 @pytest.mark.parametrize("mesh", ["bunny", "wok", "teapot"])
 def test_oracle_vs_reference_live(orc, ref, mesh):
     o = simple_scene(orc, mesh)
