@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--scene", default="bunny_scene.xml")
     ap.add_argument("--kind", type=int, default=0, help="0 = FileScene (single BVH), 1 = TLASFileScene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=7, help="HIP streams the 64-frame launches rotate over (crt_config.renderStreams)")
+    ap.add_argument("--streams", type=int, default=7, help="HIP streams the render launches rotate over (crt_config.renderStreams)")
+    ap.add_argument("--latency-probe", action="store_true", help="also time three single 64-frame steps on their own (submit, wait) after the job")
     args = ap.parse_args()
 
     import torch
@@ -154,7 +155,7 @@ def main():
 
     ctx.reserve(SPP * max(args.steps, args.warmup), 1)             # sample-slab pool for the whole job, allocated outside the timed region
     run(args.warmup)
-    ctx.timing()
+    tm_warm = ctx.timing()
     ctx.reset_counters()
     if dist is not None:
         dist.barrier()
@@ -168,14 +169,15 @@ def main():
     tm = ctx.timing()
     kernel_ms, acc_ms, launches = tm["render_kernel_ms"], tm["resolve_kernel_ms"], tm["render_launches"]
     rays = ctx.counters()["rays"]
-    # latency of ONE step on its own (submit, wait), for reference next to the pipelined throughput
+    # optional: latency of ONE step on its own (submit, wait), next to the job throughput
     lat = []
-    for i in range(3):
-        t1 = time.perf_counter()
-        ctx.render(window(i, args.steps), SPP, 1)
-        ctx.sync()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    ctx.timing()
+    if args.latency_probe:
+        for i in range(3):
+            t1 = time.perf_counter()
+            ctx.render(window(i, args.steps), SPP, 1)
+            ctx.sync()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        ctx.timing()
 
     if dist is not None:
         t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device="cuda:%d" % device)
@@ -190,10 +192,16 @@ def main():
         return
 
     ms_step = elapsed / args.steps * 1e3
-    avg_launch_ms = kernel_ms / max(launches, 1)
+    # Dominant kernel = render_tiles_kernel.  Every launch of it in this process (the warm-up job and the timed job) enters the
+    # average, so that avg_launch_ms is the figure rocprofv3 --kernel-trace --stats reports for the same command; bytes = SURVEY 8(d)'s
+    # per-ray / per-sample figures x the device counters of one step x the steps a launch covers.
+    all_launches = launches + tm_warm["render_launches"]
+    all_ms = kernel_ms + tm_warm["render_kernel_ms"]
+    avg_launch_ms = all_ms / max(all_launches, 1)
     launches_per_step = launches / args.steps
-    alg_bytes_launch = algorithmic_bytes(counts) / launches_per_step if launches_per_step > 0 else 0.0
+    alg_bytes_launch = algorithmic_bytes(counts) * (args.steps + args.warmup) / max(all_launches, 1)
     achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    job_launch_ms = kernel_ms / max(launches, 1)
     traffic = None          # HBM bytes of the job's launch from the PMC passes (tools/collect_profiles.sh), only for the workload they were collected on
     pmc_path = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(pmc_path):
@@ -217,17 +225,19 @@ def main():
                                "+ ordered accumulate), one sync at the end%s"
                                % (args.scene, "TLASFileScene" if args.kind else "FileScene", W, H, SPP, SPP, args.steps, launches,
                                   "" if world == 1 else "; every one of the %d ranks renders its own %d windows, ONE RCCL all-reduce of the float4 accumulator closes the job" % (world, args.steps)),
-                   "latency_ms_single_step": round(sorted(lat)[1], 3),
+                   "latency_ms_single_step": round(sorted(lat)[1], 3) if lat else None,
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
                    "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": "render_tiles_kernel", "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": launches_per_step,
+                     "kernel": "render_tiles_kernel", "avg_launch_ms": round(avg_launch_ms, 4), "launches": all_launches,
                      "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+                     "job_launch_ms": round(job_launch_ms, 4), "job_launch_windows": round(1 / launches_per_step, 2) if launches_per_step else None,
+                     "job_launch_achieved": round(algorithmic_bytes(counts) / max(launches_per_step, 1e-9) / (job_launch_ms * 1e-3) / 1e9, 2) if job_launch_ms > 0 else None,
                      "job_achieved": round(rays / elapsed * (algorithmic_bytes(counts) / max(counts["rays"], 1)) / 1e9, 2),
                      "accumulate_kernel_ms_per_step": round(acc_ms / args.steps, 4),
                      "counters_per_step": {k: round(v) for k, v in counts.items()},
-                     "note": "achieved = algorithmic bytes of one launch / its mean duration (HIP events on its stream); job_achieved = algorithmic GB/s over the whole timed region (incl. the ordered accumulate)"},
+                     "note": "achieved = mean algorithmic bytes per render_tiles_kernel launch / mean launch duration over all its launches in this process (warm-up job + timed job; HIP events on the launch stream) = the average rocprofv3 --stats reports; job_launch_* = the timed job's launch alone; job_achieved = algorithmic GB/s over the whole timed region incl. the ordered accumulate; the bytes are algorithmic (SURVEY 8(d)) and mostly served by L2 — traffic = HBM bytes of the job's launch from the PMC passes"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(xml, args.kind, W, H)
