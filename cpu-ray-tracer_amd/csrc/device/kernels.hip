@@ -771,10 +771,13 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                 if (cur & kRefInterior) { oa = sc.instOff + (cur & 0xffffu) * 128u; ob = oa + 32u; }                // TLAS leaf: Instance {invT rows, ids}
                 else { oa = sc.tlasOff + (cur & 0x7fffu) * 32u; ob = sc.tlasOff + ((cur >> 15) & 0x7fffu) * 32u; } // TLAS interior: the two child nodes
             }
-            // unconditional on purpose: a lane that did not move re-fetches its record (an L1 hit) and a lane with nothing to
-            // fetch reads record 0, so q0..q3 are plain loop-carried load results and nothing has to wait for them here
-            if (!live || (doneNow && h.objIdx < 2)) { oa = 0u; ob = 32u; }
-            q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, ob); q3 = ldg(geom, ob + 16u);
+            // unconditional per lane on purpose: a lane that did not move re-fetches its record (an L1 hit) and a lane with nothing to
+            // fetch reads record 0, so q0..q3 are plain loop-carried load results and nothing has to wait for them here.  Only when NO
+            // lane of the wave has a record to fetch (tiles that see only sky and floor: every ray ends at the root step) the loads —
+            // and the memory round trip the next trip would wait for — are skipped altogether.
+            const bool nothing = !live || (doneNow && h.objIdx < 2);
+            if (nothing) { oa = 0u; ob = 32u; }
+            if (__builtin_amdgcn_ballot_w64(!nothing) != 0ull) { q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, ob); q3 = ldg(geom, ob + 16u); }
         }
 #ifdef CRT_STAMPS
         CRT_STAMP(s6); stT[4] += s6 - s5; stT[5] += s6 - s0;

@@ -264,6 +264,26 @@ def test_multi_window_launch_with_partial_last_window(crt, orc):
         ctx.close(); c1.close()
 
 
+def test_sample_pool_ring_wraps_with_mixed_launch_sizes(crt, orc):
+    """The sample slabs of the launches are regions of ONE ring-allocated pool (8 windows here), recycled FIFO behind GPU-side event waits.
+    A burst of asynchronous renders of mixed sizes (1 .. 3 windows per launch, partial windows, several launches per call) wraps the
+    ring several times; the image must equal the sequential oracle's bit for bit."""
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(64, 48, max_frames_per_launch=192, render_streams=5)
+    hs.upload(ctx)
+    spp = 1
+    for frames in [64, 10, 192, 130, 5, 400, 64, 64, 33, 192, 7]:
+        ctx.render(spp, frames, 1)
+        spp += frames
+    acc = ctx.accumulator()
+    assert ctx.timing()["render_launches"] == 1 + 1 + 1 + 1 + 1 + 3 + 1 + 1 + 1 + 1 + 1
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o.renderer_init(64, 48)
+    o.render(spp - 1, 4)
+    assert np.array_equal(acc, o.accumulator())
+    assert ctx.counters()["rays"] == o.counters()["rays"]
+
+
 @pytest.mark.parametrize("streams", [1, 3, 7])
 def test_back_to_back_renders_keep_frame_order(crt, orc, streams):
     """many asynchronous crt_render calls (they overlap on `streams` HIP streams) must accumulate in frame order:
