@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--kind", type=int, default=0, help="0 = FileScene (single BVH), 1 = TLASFileScene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=7, help="HIP streams the render launches rotate over (crt_config.renderStreams)")
+    ap.add_argument("--split", choices=["frames", "tiles"], default="frames",
+                    help="N > 1: 'frames' (default, weak scaling) = every rank renders its own K windows of the full image; 'tiles' (strong scaling, BASELINE "
+                         "config 5) = the K windows of ONE image with the 16x16 tiles dealt round-robin over the ranks; both end in one RCCL all-reduce")
     ap.add_argument("--latency-probe", action="store_true", help="also time three single 64-frame steps on their own (submit, wait) after the job")
     args = ap.parse_args()
 
@@ -125,17 +128,19 @@ def main():
     W, H, SPP = args.width, args.height, args.spp
     xml = os.path.join(ASSETS, "scenes", args.scene)
     scene = crt.HostScene(xml, args.kind, ASSETS)                  # XML + OBJ + textures + SAH-BVH build on the CPU
-    ctx = crt.Context(W, H, device=device, render_streams=args.streams)
+    tiles = (W // 16) * (H // 16)
+    tsplit = crt.tile_partition(rank, world, tiles) if (world > 1 and args.split == "tiles") else (0, 1, -1)
+    ctx = crt.Context(W, H, device=device, render_streams=args.streams, tile_first=tsplit[0], tile_stride=tsplit[1], tile_count=tsplit[2])
     scene.upload(ctx)                                             # one-time flatten + copy to HBM
     acc = torch.zeros(H, W, 4, dtype=torch.float32, device="cuda:%d" % device)
     ctx.bind_accumulator(acc.data_ptr())
     def window(i, n_steps):
         """spp counter of the first frame of this rank's i-th step of an n_steps job: steps are consecutive 64-frame windows of ONE
         progressive render; rank r owns the windows r*n_steps .. r*n_steps + n_steps - 1"""
-        return crt.spp_window(rank * n_steps + i, SPP)
+        return crt.spp_window((rank * n_steps if args.split == "frames" else 0) + i, SPP)
 
     # one counted pass over the same windows with a statistics context (untimed) -> algorithmic bytes per launch
-    sctx = crt.Context(W, H, device=device, collect_stats=True)
+    sctx = crt.Context(W, H, device=device, collect_stats=True, tile_first=tsplit[0], tile_stride=tsplit[1], tile_count=tsplit[2])
     scene.upload(sctx)
     sctx.render(window(0, args.steps), SPP * args.steps, 1)      # (a statistics context renders window by window)
     sctx.sync()
@@ -218,13 +223,14 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4),
         "ms_per_frame": round(ms_step / SPP, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if args.split == "frames" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %s BVH-SAH path tracer, %dx%d, %d spp/step (passes=1, depthLimit=5); 1 step = %d frames = the next spp window of a "
                                "progressive render; the %d steps are one crt_render job (%d render_tiles_kernel launch(es), a wavefront per (tile, window), "
                                "+ ordered accumulate), one sync at the end%s"
                                % (args.scene, "TLASFileScene" if args.kind else "FileScene", W, H, SPP, SPP, args.steps, launches,
-                                  "" if world == 1 else "; every one of the %d ranks renders its own %d windows, ONE RCCL all-reduce of the float4 accumulator closes the job" % (world, args.steps)),
+                                  "" if world == 1 else ("; every one of the %d ranks renders its own %d windows, ONE RCCL all-reduce of the float4 accumulator closes the job" % (world, args.steps)
+                                                         if args.split == "frames" else "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE RCCL all-reduce of the float4 accumulator closes the job" % world)),
                    "latency_ms_single_step": round(sorted(lat)[1], 3) if lat else None,
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
                    "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},

@@ -172,6 +172,49 @@ def test_tiny_mesh_root_is_leaf_and_single_blas(crt, orc, tmp_path):
         assert ctx.counters()["mesh_hits"] > 0
 
 
+def test_many_instances_deep_tlas(crt, orc, tmp_path):
+    """40 BLAS instances (cubes / fences / teapots, three materials incl. a mirror and a dielectric) in a ring around the camera: a TLAS
+    of 2 x 40 node slots built by agglomerative clustering, rays that enter several overlapping instance boxes, deep unified LDS stack
+    (TLAS pushes + return markers + BLAS stack).  Render and FindNearest against the oracle, both scene kinds."""
+    import math
+    meshes = ["cube", "log_fence", "teapot"]
+    extra = []
+    for i in range(1, 40):
+        a = 2 * math.pi * i / 40
+        r = 3.0 + 0.7 * (i % 3)
+        extra.append((meshes[i % 3], i % 3, (round(r * math.sin(a), 3), round(-1.0 + 0.35 * (i % 4), 3), round(2.0 + r * math.cos(a), 3)),
+                      (0.0, round(37.0 * i % 360, 1), round(5.0 * (i % 5), 1)), (0.3, 0.3 + 0.05 * (i % 3), 0.3)))
+    xml = write_scene(tmp_path, "cube", pos=(0.0, -0.5, 5.0), rot=(0.0, 15.0, 0.0), scale=(0.4, 0.4, 0.4),
+                      mats=[(0.0, 0.0, (0.0, 0.0, 0.0), ""), (0.9, 0.0, (0.0, 0.0, 0.0), ""), (0.05, 0.9, (0.3, 0.1, 0.5), "")], extra_objects=extra)
+    for kind in (1, 0):
+        hs = crt.HostScene(xml, kind, ASSETS)
+        o, _ = orc.load_scene(xml, kind, ASSETS)
+        if kind == 1:
+            assert hs.bvh_count() == 40
+            (na, ua), (nb, ub) = hs.tlas(), o.tlas()
+            assert ua == ub == 80 and np.array_equal(na.view(np.uint8), nb.view(np.uint8))
+        ctx = crt.Context(128, 96, collect_stats=True)
+        hs.upload(ctx)
+        ctx.set_camera_state((0.0, 0.5, 2.0), (0.3, 0.3, 3.0))
+        ctx.render(1, 3, 1)
+        o.renderer_init(128, 96)
+        o.set_camera_state((0.0, 0.5, 2.0), (0.3, 0.3, 3.0))
+        o.render(3, 4)
+        assert np.array_equal(ctx.accumulator(), o.accumulator()), kind
+        assert ctx.counters() == o.counters()
+        assert ctx.counters()["mesh_hits"] > 5000
+        rng = np.random.default_rng(5)
+        O = np.tile(np.array([0.0, 0.5, 2.0], np.float32), (4000, 1)) + rng.uniform(-0.2, 0.2, (4000, 3)).astype(np.float32)
+        D = rng.normal(size=(4000, 3)).astype(np.float32); D[:, 1] *= 0.3
+        D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+        g, c = ctx.find_nearest(O, D), o.find_nearest(O, D)
+        for f in ("objIdx", "triIdx", "traversed", "tested"):
+            assert np.array_equal(g[f], c[f]), (kind, f)
+        for f in ("t", "u", "v"):
+            assert np.array_equal(bits(g[f]), bits(c[f])), (kind, f)
+        ctx.close()
+
+
 def test_axis_aligned_rays_nan_exact_slab_path(crt, orc):
     """direction components that are exactly 0 make rD infinite and 0*inf = NaN in the slab test: the kernel must fall back
     to the reference's std::min/std::max operand order (box_exact) and still agree bit for bit"""
