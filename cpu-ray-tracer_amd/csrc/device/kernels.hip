@@ -1,18 +1,20 @@
 // kernels.hip — hand-written gfx950 (CDNA4) kernels of the path-tracing hot path.
 //
-//   render_tiles_kernel   one 64-lane wavefront per 16x16 image tile; lane f owns the RNG stream of frame f of that
-//                         tile (the reference seeds one xorshift32 stream per (tile, frame) and consumes it serially
-//                         over the tile's 256 pixels — "3. PathTracer/renderer.cpp":117-131).  The wave is a small
-//                         wavefront pipeline of its own: every lane is a state machine {needs shading / ray-gen,
-//                         at a TLAS node, at a BVH interior node, at a leaf triangle}, and each trip of the wave's
-//                         loop executes ONE phase, chosen from __ballot population counts, for the lanes that are in
-//                         it.  Lanes never wait for the longest ray of the wave: a lane whose path ends regenerates
-//                         its next pixel's primary ray and re-enters traversal while its neighbours keep walking.
-//                         Traversal stacks are per-lane columns in LDS.  Finished paths write their radiance sample
-//                         to the sample slab in HBM.
-//   accumulate_kernel     adds the slab's samples to the float4 accumulator in frame order (bit-exact with the
-//                         reference's `accumulator[..] +=` order, renderer.cpp:124) — no float atomics anywhere.
+//   render_tiles_kernel   one 64-lane wavefront per (16x16 image tile, 64-frame window); lane f owns the RNG stream of frame f
+//                         of that tile (the reference seeds one xorshift32 stream per (tile, frame) and consumes it serially
+//                         over the tile's 256 pixels — "3. PathTracer/renderer.cpp":117-131).  One grid covers every window
+//                         of a crt_render job, expensive tiles first.  The wave is a small wavefront pipeline of its own:
+//                         every lane is a state machine {needs shading / ray-gen, at a TLAS node, at a BVH interior node, at
+//                         a leaf triangle}, and each trip of the wave's loop runs the phases that have lanes waiting
+//                         (ballot population counts).  Lanes never wait for the longest ray of the wave: a lane whose path
+//                         ends regenerates its next pixel's primary ray and re-enters traversal while its neighbours keep
+//                         walking.  Traversal stacks and the paths' throughput factors are per-lane columns in LDS.
+//                         Finished paths write their radiance sample to the sample slab in HBM.
+//   accumulate_kernel     adds the slab's samples to the float4 accumulator in (window, frame, pass) order (bit-exact with the
+//                         reference's `accumulator[..] +=` order, renderer.cpp:124), streaming the slab at HBM rate — no float
+//                         atomics anywhere.
 //   find_nearest_kernel   scene.FindNearest for a ray buffer (parity / query entry).
+//   whitted_kernel        the Whitted-style integrator ("2. WhittedStyle/renderer.cpp":21-157), one thread per pixel.
 //   resolve_kernel        screen pixels + per-tile energy sums (renderer.cpp:119,127-129).
 //
 // Numerics: compiled with -ffp-contract=off; only IEEE + - * / sqrt, so results are bit-identical with a scalar
@@ -350,21 +352,21 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// render_tiles_kernel<KIND, COUNT>: grid = tiles owned by this ctx, block = one wavefront (lane = frame).
+// render_tiles_kernel<KIND, COUNT>: grid = (tiles owned by this ctx) x (64-frame windows of the launch), block = one wavefront (lane = frame).
 // slab layout: float4 [window][tileLocal][sample 0..S)[pixel 0..255], S = frames*passes of the window, sample = frame*passes + pass
 // (sample-major inside a tile: accumulate_kernel's 256 threads read 4 KB rows; the stores here are scattered either way)
 //
 // Per-lane traversal state is ONE packed reference `cur` (layout.h), the 64-byte record it names — already
-// PRE-LOADED into registers q0..q3 by the trip that produced it — and a stack whose top lives in a register:
+// PRE-LOADED into registers q0..q3 by the trip that produced it — and a stack in a per-lane LDS column:
 //     cur == 0 (done)      -> SHADE phase: shade the hit with the pre-loaded ShadeTri (or end the path: unwind, write the
 //                             sample, generate the next pixel's primary ray), start FindNearest for the new ray (quad,
-//                             plane), cur = root
+//                             plane, first traversal step from the root's child pair in the kernel arguments)
 //     BVH interior         -> NODE phase: two slab tests on the pre-loaded NodePair, ordered descend / push / pop
 //     BVH leaf             -> TRI phase: ONE Möller–Trumbore test on the pre-loaded LeafTri, next triangle or pop
 //     TLAS interior / leaf -> TLAS phase (two-level scenes): two slab tests on the pre-loaded child nodes / enter the
 //                             BLAS through the pre-loaded invT rows
-// One trip of the wave's loop = ballot the states, run each phase that has enough lanes (thresholds below; a phase
-// always runs when nothing else can), then issue the record loads for every lane that moved: four 16-byte loads at
+// One trip of the wave's loop = ballot the states, run each phase that has enough lanes (thresholds below: SHADE waits
+// for 24 lanes unless nothing else can run, the others run whenever populated), then issue the record loads: four 16-byte loads at
 // `geom + 32-bit offset`.  The loads fly while the next trip's ballots and the other phases' arithmetic execute, and a
 // lane only ever pays for its own ray's length, never for the longest ray in the wave.
 // ------------------------------------------------------------------------------------------------------------
