@@ -6,8 +6,8 @@
  * path and the CPU baseline of bench.py.  Nothing under cpu-ray-tracer_amd/ may include, link or call it.
  *
  * PINNING STATUS (see DESIGN.md §"Oracle"):
- *   - pinned by the real reference, compiled unpatched where it lies (oracle/_ref, tests/test_oracle_vs_ref.py):
- *       BVH build (node array, triangleIndices order), IntersectAABB / IntersectTri / IntersectBVH results
+ *   - pinned by the real reference, compiled unpatched where it lies (oracle/_ref; tests/test_oracle_pinning.py live + tests/golden ref_*):
+ *       BVH build (node array, triangleIndices order), BVH::Refit, IntersectAABB / IntersectTri / IntersectBVH results
  *       [infra/bvh.cpp — blas_bvh.cpp's build/traverse code is textually identical modulo names],
  *       OBJ triangulation + float parsing [lib/tiny_obj_loader.h], texture decode [lib/stb_image.h].
  *   - PARITY UNPINNED (restated line by line from the cited reference lines, no executable reference
