@@ -9,11 +9,13 @@
  *   - pinned by the real reference, compiled unpatched where it lies (oracle/_ref; tests/test_oracle_pinning.py live + tests/golden ref_*):
  *       BVH build (node array, triangleIndices order), BVH::Refit, IntersectAABB / IntersectTri / IntersectBVH results
  *       [infra/bvh.cpp — blas_bvh.cpp's build/traverse code is textually identical modulo names],
- *       OBJ triangulation + float parsing [lib/tiny_obj_loader.h], texture decode [lib/stb_image.h].
+ *       OBJ triangulation + float parsing [lib/tiny_obj_loader.h], texture decode [lib/stb_image.h],
+ *       Camera default frustum / SetCameraState / GetPrimaryRay [template/camera.h], Texture packing + Sample, Material::GetAlbedo
+ *       [template/texture.h, material.h].
  *   - PARITY UNPINNED (restated line by line from the cited reference lines, no executable reference
  *     and no reference-held golden vector exists: the reference has no tests and is MSVC/Windows-only):
- *       Renderer::Sample/ProcessTile/Tick, RNG use, Camera, Quad/Plane, TLAS build + traversal,
- *       BLAS instance transforms, GetHitInfo, skydome/texture lookup, scene assembly.
+ *       Renderer::Sample/ProcessTile/Tick, RNG, Quad/Plane, TLAS build + traversal,
+ *       BLAS instance transforms, GetHitInfo, skydome lookup, scene assembly.
  *
  * Conventions pinned here (reference leaves them to the compiler; DESIGN.md "pinned choices"):
  *   - argument evaluation order = MSVC's right-to-left: in GetPrimaryRay(x+rnd, y+rnd) the FIRST draw is the
@@ -1014,6 +1016,23 @@ int orc_set_camera_state(orc_ctx* c, const float p[3], const float t[3]) // came
 int orc_get_camera(orc_ctx* c, float p[3], float tl[3], float tr[3], float bl[3])
 {
     st3(p, c->camPos); st3(tl, c->topLeft); st3(tr, c->topRight); st3(bl, c->bottomLeft); return 0;
+}
+// Camera::GetPrimaryRay (template/camera.h:23-30) for given pixel coordinates (jitter included by the caller)
+int orc_primary_rays(orc_ctx* c, const float* xy, size_t n, float* O, float* D)
+{
+    if (c->W <= 0) return -1;
+    for (size_t i = 0; i < n; i++) {
+        const Ray r = c->primary_ray(xy[2 * i], xy[2 * i + 1]);
+        st3(O + 3 * i, r.O); st3(D + 3 * i, r.D);
+    }
+    return 0;
+}
+// Texture::Sample (template/texture.h:61-96) on caller-provided 0x00RRGGBB texels
+int orc_texture_sample(const uint32_t* px, int w, int h, const float* uv, size_t n, float* rgb)
+{
+    Tex t; t.px.assign(px, px + (size_t)w * h); t.w = w; t.h = h;
+    for (size_t i = 0; i < n; i++) st3(rgb + 3 * i, t.sample(uv[2 * i], uv[2 * i + 1]));
+    return 0;
 }
 int orc_set_params(orc_ctx* c, int depthLimit, int passes) { c->depthLimit = depthLimit; c->passes = passes; return 0; }
 int orc_clear(orc_ctx* c) { std::fill(c->acc.begin(), c->acc.end(), 0.0f); c->spp = 1; return 0; }

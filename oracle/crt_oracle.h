@@ -78,6 +78,8 @@ int orc_tlas_copy(orc_ctx*, orc_tlas_node* nodes /*2*blasCount*/, uint32_t* node
 int orc_renderer_init(orc_ctx*, int width, int height);        /* Renderer::Init + default Camera() */
 int orc_set_camera_state(orc_ctx*, const float pos[3], const float target[3]);
 int orc_get_camera(orc_ctx*, float camPos[3], float topLeft[3], float topRight[3], float bottomLeft[3]);
+int orc_primary_rays(orc_ctx*, const float* xy /* 2n: pixel coordinates incl. jitter */, size_t n, float* O /* 3n */, float* D /* 3n */);   /* Camera::GetPrimaryRay */
+int orc_texture_sample(const uint32_t* texels, int w, int h, const float* uv /* 2n */, size_t n, float* rgb /* 3n */);                        /* Texture::Sample */
 int orc_set_params(orc_ctx*, int depthLimit, int passes);
 int orc_clear(orc_ctx*);                                       /* ClearAccumulator + spp = 1 */
 int orc_set_spp(orc_ctx*, int spp);

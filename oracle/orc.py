@@ -193,6 +193,13 @@ class Oracle:
         self._ck(self.L.orc_get_camera(self.h, *[_fp(x) for x in a]))
         return a
 
+    def primary_rays(self, xy):
+        """Camera::GetPrimaryRay of the oracle for pixel coordinates xy (n, 2)"""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        O = np.zeros((xy.shape[0], 3), np.float32); D = np.zeros((xy.shape[0], 3), np.float32)
+        self._ck(self.L.orc_primary_rays(self.h, _fp(xy), C.c_size_t(xy.shape[0]), _fp(O), _fp(D)))
+        return O, D
+
     def set_params(self, depth_limit=5, passes=1):
         self._ck(self.L.orc_set_params(self.h, depth_limit, passes))
 
@@ -261,6 +268,14 @@ class Oracle:
 # ================================================================================================
 # independent asset readers (pure Python / numpy)
 # ================================================================================================
+def texture_sample(texels, uv):
+    """Texture::Sample of the oracle on (h, w) uint32 texels"""
+    texels = np.ascontiguousarray(texels, np.uint32); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    rgb = np.zeros((uv.shape[0], 3), np.float32)
+    lib().orc_texture_sample(_fp(texels), texels.shape[1], texels.shape[0], _fp(uv), C.c_size_t(uv.shape[0]), _fp(rgb))
+    return rgb
+
+
 def read_obj(path):
     """OBJ -> (pos[n,3], nrm[n,3], uv[n,2]) per triangle corner, triangulated with tinyobjloader v2.0's rules
     (reference lib/tiny_obj_loader.h:1480-1700): triangles pass through, quads split along the shorter diagonal
@@ -555,6 +570,7 @@ class Ref:
         L.ref_bvh_build.restype = C.c_void_p
         L.ref_obj_load.restype = C.c_void_p
         L.ref_image_load.restype = C.POINTER(C.c_ubyte)
+        L.ref_texture_load.restype = C.POINTER(C.c_uint32)
         self.L = L
 
     def bvh_build(self, tris):
@@ -601,6 +617,31 @@ class Ref:
         self.L.ref_obj_copy(h, _fp(pos), _fp(nrm), _fp(uv))
         self.L.ref_obj_free(h)
         return pos, nrm, uv
+
+    def camera_rays(self, xy, pos_target=None):
+        """the reference's Camera (1024 x 640): default frustum or SetCameraState(pos, target); returns (corners[4,3], O, D)"""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        pt = None if pos_target is None else np.ascontiguousarray(np.concatenate([np.asarray(pos_target[0], np.float32), np.asarray(pos_target[1], np.float32)]), np.float32)
+        corners = np.zeros((4, 3), np.float32); O = np.zeros((xy.shape[0], 3), np.float32); D = np.zeros((xy.shape[0], 3), np.float32)
+        self.L.ref_camera_rays(None if pt is None else _fp(pt), _fp(xy), C.c_uint32(xy.shape[0]), _fp(corners), _fp(O), _fp(D))
+        return corners, O, D
+
+    def texture_load(self, path):
+        """Texture::LoadFromFile's own packing: (h, w) uint32 0x00RRGGBB"""
+        w, h = C.c_int(), C.c_int()
+        p = self.L.ref_texture_load(path.encode(), C.byref(w), C.byref(h))
+        if not p:
+            raise RuntimeError("Texture::LoadFromFile failed on " + path)
+        a = np.ctypeslib.as_array(p, shape=(h.value, w.value)).copy()
+        self.L.ref_free(p)
+        return a
+
+    def texture_sample(self, texels, uv):
+        """Texture::Sample and Material::GetAlbedo of the reference on (h, w) uint32 texels; returns (rgb, albedo)"""
+        texels = np.ascontiguousarray(texels, np.uint32); uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        rgb = np.zeros((uv.shape[0], 3), np.float32); alb = np.zeros((uv.shape[0], 3), np.float32)
+        self.L.ref_texture_sample(_fp(texels), texels.shape[1], texels.shape[0], _fp(uv), C.c_uint32(uv.shape[0]), _fp(rgb), _fp(alb))
+        return rgb, alb
 
     def image_load(self, path):
         w, h, n = C.c_int(), C.c_int(), C.c_int()

@@ -5,7 +5,7 @@
  * from where they lie (-I/root/reference/{template,infra,lib,lib/imgui}).  The reference's full precomp.h
  * cannot be used: it needs <io.h>, "windows.h" and <intrin.h> (template/precomp.h:15,82,223), which this image
  * lacks; writing substitutes for those is not allowed, so only translation units that compile without them
- * are built here (infra/bvh.cpp, lib/tiny_obj_loader.h, lib/stb_image.h).
+ * are built here (infra/bvh.cpp, template/camera.h + texture.h + material.h, lib/tiny_obj_loader.h, lib/stb_image.h; see ref_harness.cpp).
  * infra/bvh.cpp's `#include "precomp.h"` resolves to this file because -Iref_build precedes the reference paths.
  */
 #pragma once

@@ -5,6 +5,15 @@
  *   infra/bvh.cpp            -> BVH::Build, BVH::Refit, BVH::Intersect (IntersectBVH / IntersectAABB / IntersectTri)
  *   lib/tiny_obj_loader.h    -> tinyobj::LoadObj (float parsing, quad / polygon triangulation)
  *   lib/stb_image.h          -> stbi_load (PNG / JPG / TGA decode)
+ *   template/camera.h        -> Camera(): default frustum, GetPrimaryRay, SetCameraState (compiled for its fixed SCRWIDTH x SCRHEIGHT = 1024 x 640)
+ *   template/texture.h       -> Texture::LoadFromFile (0x00RRGGBB packing), Texture::Sample
+ *   template/material.h      -> Material::GetAlbedo
+ * The three headers need three names that template/precomp.h / template/opengl.h declare and that live in translation units this
+ * image cannot build (template.cpp, opencl.cpp: <windows.h>, OpenGL, OpenCL): IsKeyDown (precomp.h:143), WindowHasFocus (opengl.h:23)
+ * and FatalError (precomp.h:203).  They are DECLARED below exactly as there and never defined: only Camera::HandleInput and the
+ * Texture(path) constructor use them, neither is instantiated here, so nothing is emitted that would need them.  Build flags:
+ * -fno-access-control (the harness fills Texture's private texel vector), -Wno-non-pod-varargs (texture.h:45 passes a std::string through
+ * FatalError's varargs), -DGLFW_INCLUDE_NONE (the reference's own lib/GLFW/include/GLFW/glfw3.h provides GLFW_KEY_*; no system GL headers).
  */
 #include "precomp.h"
 #include "bvh.cpp"                     /* /root/reference/infra/bvh.cpp, unmodified */
@@ -17,8 +26,17 @@
 #define TINYOBJLOADER_IMPLEMENTATION
 #include "tiny_obj_loader.h"           /* /root/reference/lib/tiny_obj_loader.h */
 
+#include "GLFW/glfw3.h"                /* /root/reference/lib/GLFW/include/GLFW/glfw3.h (GLFW_KEY_* used by camera.h) */
+bool IsKeyDown( const uint key );      /* template/precomp.h:143 (declaration only) */
+bool WindowHasFocus();                 /* template/opengl.h:23   (declaration only) */
+void FatalError( const char* fmt, ... ); /* template/precomp.h:203 (declaration only) */
+#include "camera.h"                    /* /root/reference/template/camera.h */
+#include "texture.h"                   /* /root/reference/template/texture.h */
+#include "material.h"                  /* /root/reference/template/material.h */
+
 #include <stdint.h>
 
+static_assert(SCRWIDTH == 1024 && SCRHEIGHT == 640, "camera.h resolution");
 static_assert(sizeof(Tri) == 112, "Tri layout");
 static_assert(sizeof(BVHNode) == 32, "BVHNode layout");
 
@@ -93,5 +111,43 @@ void ref_obj_free(void* h) { delete (ref_obj*)h; }
 /* stb_image: raw decoded bytes + channel count, as Texture::LoadFromFile receives them (template/texture.h:18) */
 unsigned char* ref_image_load(const char* path, int* w, int* h, int* n) { return stbi_load(path, w, h, n, 0); }
 void ref_image_free(unsigned char* p) { stbi_image_free(p); }
+
+/* Camera (template/camera.h:14-30, 61-73): default frustum or SetCameraState(pos, target); rays for n pixel coordinates */
+void ref_camera_rays(const float* pos_target /* 6 floats or NULL = default Camera() */, const float* xy, uint32_t n, float* corners /* camPos, TL, TR, BL */, float* O, float* D)
+{
+    Camera cam;
+    if (pos_target) cam.SetCameraState(float3(pos_target[0], pos_target[1], pos_target[2]), float3(pos_target[3], pos_target[4], pos_target[5]));
+    const float3 c[4] = {cam.camPos, cam.topLeft, cam.topRight, cam.bottomLeft};
+    for (int k = 0; k < 4; k++) { corners[3 * k] = c[k].x; corners[3 * k + 1] = c[k].y; corners[3 * k + 2] = c[k].z; }
+    for (uint32_t i = 0; i < n; i++) {
+        Ray r = cam.GetPrimaryRay(xy[2 * i], xy[2 * i + 1]);
+        O[3 * i] = r.O.x; O[3 * i + 1] = r.O.y; O[3 * i + 2] = r.O.z; D[3 * i] = r.D.x; D[3 * i + 1] = r.D.y; D[3 * i + 2] = r.D.z;
+    }
+}
+/* Texture::LoadFromFile's packing (template/texture.h:15-39): returns width * height texels, 0x00RRGGBB */
+uint32_t* ref_texture_load(const char* path, int* w, int* h)
+{
+    Texture t; t.LoadFromFile(path);
+    if (t.pixels.empty()) return nullptr;
+    *w = t.width; *h = t.height;
+    uint32_t* out = (uint32_t*)malloc(t.pixels.size() * 4);
+    memcpy(out, t.pixels.data(), t.pixels.size() * 4);
+    return out;
+}
+void ref_free(void* p) { free(p); }
+/* Texture::Sample (template/texture.h:61-96) and Material::GetAlbedo (template/material.h:28-35) on caller-provided texels */
+void ref_texture_sample(const uint32_t* px, int w, int h, const float* uv, uint32_t n, float* rgb, float* albedo)
+{
+    Material m;
+    m.textureDiffuse = std::make_unique<Texture>();
+    Texture& t = *m.textureDiffuse;
+    t.pixels.assign(px, px + (size_t)w * h); t.width = w; t.height = h;
+    for (uint32_t i = 0; i < n; i++) {
+        const float3 c = t.Sample(uv[2 * i], uv[2 * i + 1]);
+        rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+        const float3 a = m.GetAlbedo(float2(uv[2 * i], uv[2 * i + 1]));
+        albedo[3 * i] = a.x; albedo[3 * i + 1] = a.y; albedo[3 * i + 2] = a.z;
+    }
+}
 
 } // extern "C"

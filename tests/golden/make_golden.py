@@ -86,6 +86,24 @@ def main():
             out.setdefault("ref_refit", {})[m] = dict(nodes=crc(ref.bvh_move_and_refit(h, moved)), moved=crc(moved))
         ref.bvh_free(h)
     np.savez_compressed(os.path.join(HERE, "ref_bvh_rays.npz"), **{"%s_%s" % (m, k): v for m, d in rays.items() for k, v in d.items()})
+    # --- ref_camera: the reference's Camera (template/camera.h, compiled for 1024 x 640): default frustum and SetCameraState -----
+    rng = np.random.default_rng(77)
+    xy = np.concatenate([rng.uniform(0, [1024, 640], (500, 2)), [[0, 0], [1023.999, 639.999], [512, 320], [0.5, 0.25]]]).astype(np.float32)
+    cams = {"default": None, "look": ((0.5, 1.25, -3.0), (0.0, 0.0, 2.0)), "side": ((4.0, 0.5, 2.0), (0.0, -0.5, 2.0))}
+    cam_out = {}
+    for name, pt in cams.items():
+        corners, O, D = ref.camera_rays(xy, pt)
+        cam_out[name] = dict(pos_target=pt, corners=crc(corners), O=crc(O), D=crc(D))
+    out["ref_camera"] = dict(xy=crc(xy), cams=cam_out)
+    np.save(os.path.join(HERE, "ref_camera_xy.npy"), xy)
+    # --- ref_texture: Texture::LoadFromFile packing, Texture::Sample and Material::GetAlbedo of the reference -----------------------
+    tex = ref.texture_load(os.path.join(RA, "textures/Stylized_Pavement_basecolor.png"))
+    uv = np.concatenate([rng.uniform(-0.25, 1.25, (2000, 2)), [[0, 0], [1, 1], [1, 0], [0, 1], [0.5, 0.5], [0.999999, 1e-7]]]).astype(np.float32)
+    rgb, alb = ref.texture_sample(tex, uv)
+    out["ref_texture"] = dict(file="textures/Stylized_Pavement_basecolor.png", texels=crc(tex), uv=crc(uv), rgb=crc(rgb), albedo=crc(alb),
+                              tga=crc(ref.texture_load(os.path.join(RA, "textures/Stylized_Wood_basecolor.tga"))),
+                              jpg=crc(ref.texture_load(os.path.join(RA, "textures/Wood_Tower_Col.jpg"))))
+    np.save(os.path.join(HERE, "ref_texture_uv.npy"), uv)
     # --- orc_render: oracle accumulators of the BASELINE scenes at small sizes (regression vectors) ------------------
     out["orc_render"] = {}
     for name, xml, kind, W, H, frames in [("bunny", "bunny_scene.xml", 0, 96, 64, 4), ("tlas", "tlas_scene.xml", 1, 96, 64, 3),

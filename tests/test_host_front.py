@@ -87,6 +87,25 @@ def test_refit_matches_oracle(crt, orc, xml, kind):
         hs.move_and_refit(i, moved[:-1])
 
 
+def test_host_camera_and_textures_match_reference_golden(crt):
+    """host front vs the REAL reference's outputs (tests/golden ref_camera / ref_texture, made by oracle/_ref): Camera::SetCameraState's
+    frustum corners at the resolution template/camera.h is compiled for, and the texels of Texture::LoadFromFile for PNG / TGA / JPEG"""
+    import json, zlib
+    G = json.load(open(os.path.join(REPO, "tests", "golden", "golden.json")))
+    crc = lambda a: int(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff)
+    for name, g in G["ref_camera"]["cams"].items():
+        if g["pos_target"] is None:
+            continue
+        a = [(C.c_float * 3)() for _ in range(4)]
+        pos, tgt = g["pos_target"]
+        assert crt.lib().crt_host_camera_state(1024, 640, (C.c_float * 3)(*pos), (C.c_float * 3)(*tgt), *a) == 0
+        assert crc(np.array([list(x) for x in a], np.float32)) == g["corners"], name
+    t = G["ref_texture"]
+    assert crc(crt.load_image(os.path.join(ASSETS, t["file"]))) == t["texels"]
+    assert crc(crt.load_image(os.path.join(ASSETS, "textures", "Stylized_Wood_basecolor.tga"))) == t["tga"]
+    assert crc(crt.load_image(os.path.join(ASSETS, "textures", "Wood_Tower_Col.jpg"))) == t["jpg"]
+
+
 def test_jpeg_loader_matches_stb_golden(crt):
     """Baseline JPEG in the host loader: texels must be the ones the reference's stbi_load produces (template/texture.h:18).
     tests/golden/jpeg/*.jpg were decoded by the REAL lib/stb_image.h (oracle/_ref) when the fixtures were made

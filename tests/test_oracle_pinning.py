@@ -79,6 +79,38 @@ def test_oracle_traversal_matches_reference_golden(orc, mesh):
     assert np.array_equal(h["tested"][miss], z[mesh + "_tested"][miss])
 
 
+def camera_oracle(orc, pos_target):
+    o = orc.Oracle(0)
+    o.renderer_init(1024, 640)                       # the resolution template/camera.h is compiled for (SCRWIDTH x SCRHEIGHT)
+    if pos_target is not None:
+        o.set_camera_state(*pos_target)
+    return o
+
+
+@pytest.mark.parametrize("name", sorted(G["ref_camera"]["cams"].keys()))
+def test_oracle_camera_matches_reference_golden(orc, name):
+    """Camera(): default frustum, SetCameraState and GetPrimaryRay of the real reference (template/camera.h:14-30, 61-73)"""
+    g = G["ref_camera"]["cams"][name]
+    xy = np.load(os.path.join(GOLDEN, "ref_camera_xy.npy"))
+    assert crc(xy) == G["ref_camera"]["xy"]
+    o = camera_oracle(orc, g["pos_target"])
+    assert crc(np.stack(o.camera())) == g["corners"]
+    O, D = o.primary_rays(xy)
+    assert (crc(O), crc(D)) == (g["O"], g["D"])
+
+
+def test_oracle_texture_matches_reference_golden(orc):
+    """Texture::LoadFromFile's packing, Texture::Sample and Material::GetAlbedo of the real reference (template/texture.h, material.h)"""
+    g = G["ref_texture"]
+    tex = orc.pack_rgb(orc.read_image(os.path.join(ASSETS, g["file"])))
+    assert crc(tex) == g["texels"]
+    assert crc(orc.pack_rgb(orc.read_image(os.path.join(ASSETS, "textures/Stylized_Wood_basecolor.tga")))) == g["tga"]
+    uv = np.load(os.path.join(GOLDEN, "ref_texture_uv.npy"))
+    assert crc(uv) == g["uv"]
+    rgb = orc.texture_sample(tex, uv)
+    assert crc(rgb) == g["rgb"] == g["albedo"]
+
+
 def deform(p):
     """vertex animation stand-in (same as tests/golden/make_golden.py): p + 0.1 * (p.yzx * p.zxy), float32 products and sums only"""
     p = np.asarray(p, np.float32)
@@ -101,6 +133,25 @@ def test_oracle_refit_matches_reference_golden(orc, mesh):
 # ---------------------------------------------------------------------------------------------------------------
 # live comparison with the real reference (authoring container)
 # ---------------------------------------------------------------------------------------------------------------
+def test_oracle_camera_and_texture_vs_reference_live(orc, ref):
+    rng = np.random.default_rng(3)
+    xy = rng.uniform(-2, [1026, 642], (4000, 2)).astype(np.float32)
+    for pt in (None, ((0.5, 1.25, -3.0), (0.0, 0.0, 2.0)), ((-2.0, 3.0, 1.0), (0.0, -1.0, 2.5))):
+        corners, O, D = ref.camera_rays(xy, pt)
+        o = camera_oracle(orc, pt)
+        assert np.array_equal(np.stack(o.camera()).view(np.uint32), corners.view(np.uint32))
+        oO, oD = o.primary_rays(xy)
+        assert np.array_equal(oO.view(np.uint32), O.view(np.uint32)) and np.array_equal(oD.view(np.uint32), D.view(np.uint32))
+    for f in ("textures/Stylized_Pavement_basecolor.png", "textures/Stylized_Wood_basecolor.tga", "textures/Defuse_wok.png"):
+        tex = ref.texture_load(os.path.join(ASSETS, f))
+        assert np.array_equal(tex, orc.pack_rgb(orc.read_image(os.path.join(ASSETS, f)))), f
+    uv = rng.uniform(-0.5, 1.5, (20000, 2)).astype(np.float32)
+    small = rng.integers(0, 1 << 24, (37, 53)).astype(np.uint32)
+    for tex in (ref.texture_load(os.path.join(ASSETS, "textures/Stylized_Pavement_basecolor.png")), small):
+        rgb, alb = ref.texture_sample(tex, uv)
+        assert np.array_equal(orc.texture_sample(tex, uv).view(np.uint32), rgb.view(np.uint32)) and np.array_equal(rgb, alb)
+
+
 @pytest.mark.parametrize("mesh", ["bunny", "wok"])
 def test_oracle_refit_vs_reference_live(orc, ref, mesh):
     o = simple_scene(orc, mesh)
