@@ -78,14 +78,21 @@ def test_render_matches_oracle(crt, orc, xml, kind, W, H, frames):
 
 
 @pytest.mark.parametrize("switch", ["CRT_DEBUG_GENERAL_PRIMS", "CRT_DEBUG_NO_ROOTPAIR"])
-@pytest.mark.parametrize("xml,kind", [("bunny_scene.xml", 0), ("tlas_scene.xml", 1)])
-def test_general_code_paths_are_bit_identical(crt, monkeypatch, switch, xml, kind):
+@pytest.mark.parametrize("xml,kind", [("bunny_scene.xml", 0), ("tlas_scene.xml", 1), ("light_at_origin", 0)])
+def test_general_code_paths_are_bit_identical(crt, monkeypatch, tmp_path, switch, xml, kind):
     """The render kernel takes two shortcuts that crt_upload_scene enables per scene: the short quad / plane tests when the light
     is an unrotated quad and the floor normal is (0,1,0) (what FileScene / TLASFileScene always build), and every ray's first
     traversal step from the root's child pair held in the kernel arguments.  The debug switches force the general expressions /
     the plain root start on the same scenes: image, ray count and traversal counters must not change by a bit."""
     W, H, frames = 128, 96, 3
-    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    if xml == "light_at_origin":      # light quad in the plane y = 0 through the origin: the translation terms of its invT are zeros (of either sign)
+        p = tmp_path / "l0.xml"
+        p.write_text(open(scene_path("bunny_scene.xml")).read().replace("<light_position><x>0.0</x><y>3.0</y><z>1.0</z></light_position>",
+                                                                         "<light_position><x>0.0</x><y>0.0</y><z>0.0</z></light_position>"))
+        assert "<y>0.0</y><z>0.0</z></light_position>" in p.read_text()
+        hs = crt.HostScene(str(p), kind, ASSETS)
+    else:
+        hs = crt.HostScene(scene_path(xml), kind, ASSETS)
     out = []
     for forced in (False, True):
         if forced:
