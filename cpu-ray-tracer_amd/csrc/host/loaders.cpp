@@ -330,19 +330,22 @@ Raw decodeTga(const std::string& d, const std::string& path)
     return r;
 }
 
-// ---- baseline JPEG ------------------------------------------------------------------------------------------------------
-// Sequential Huffman JPEG (SOF0 / SOF1, 8 bit, 1 or 3 components, any sampling factors, restart intervals).  A texture's texels must
+// ---- JPEG ---------------------------------------------------------------------------------------------------------------
+// Huffman JPEG, sequential (SOF0 / SOF1) and progressive (SOF2: spectral selection + successive approximation, ITU T.81 annex G),
+// 8 bit, 1 or 3 components, any sampling factors, restart intervals.  A texture's texels must
 // be the ones the reference gets from stbi_load (template/texture.h:18), and JPEG leaves the arithmetic of the decoder open, so this
 // follows the arithmetic lib/stb_image.h uses, stage by stage:
-//   coefficients  (short)(value * quantiser)                                            stbi__jpeg_decode_block, :2182-2233
+//   coefficients  (short)(value * quantiser); progressive: 16-bit coefficients accumulated over the scans, then multiplied by the
+//                 quantiser in 16-bit arithmetic                                         stbi__jpeg_decode_block, :2182-2233; :2236-2380, :3038-3062
 //   inverse DCT   the 12-bit fixed-point "islow" butterfly, column pass rounded to 2 extra bits (+512 >> 10), row pass
 //                 +65536 + (128 << 17) >> 17, clamped                                   stbi__idct_block, :2393-2495
 //   upsampling    1x1 copy; 2x1 / 1x2 / 2x2 triangle filters (3:1 weights), anything else nearest; the row pairing of
 //                 load_jpeg_image's line0 / line1 / ystep walk                          :3411-3604, :3845-3893
 //   colour        YCbCr -> RGB in 20-bit fixed point with the 0xffff0000 mask on the Cb term of G; components tagged 'R','G','B', or an
 //                 Adobe APP14 transform 0 without a JFIF header, are taken as RGB         stbi__YCbCr_to_RGB_row :3606-3631, :3825
-// Progressive, arithmetic-coded, 12-bit and 4-component files are rejected with a message.
-struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, w2 = 0, h2 = 0, x = 0, y = 0, pred = 0; std::vector<uint8_t> plane; };
+// Arithmetic-coded, lossless, 12-bit and 4-component files are rejected with a message.
+struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, w2 = 0, h2 = 0, x = 0, y = 0, pred = 0; std::vector<uint8_t> plane;
+                  std::vector<short> coef; };   // coef: progressive files only, 64 per 8x8 block, (w2 / 8) blocks per row
 struct JpegHuff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool present = false; };
 
 struct JpegBits {
@@ -475,7 +478,7 @@ Raw decodeJpeg(const std::string& d, const std::string& path)
     const uint8_t* p = (const uint8_t*)d.data(); const size_t size = d.size();
     uint16_t quant[4][64]; bool haveQ[4] = {false, false, false, false};
     JpegHuff hdc[4], hac[4];
-    std::vector<JpegComp> comp; int W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, adobe = -1; bool jfif = false, haveFrame = false, decoded = false;
+    std::vector<JpegComp> comp; int W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, adobe = -1; bool jfif = false, haveFrame = false, decoded = false, progressive = false;
     size_t o = 2;
     auto need = [&](size_t n) { if (o + n > size) fail(path + ": truncated JPEG"); };
     for (;;) {
@@ -514,7 +517,7 @@ Raw decodeJpeg(const std::string& d, const std::string& path)
         } else if (m == 0xDD) { if (n < 2) fail(path + ": corrupt JPEG (DRI)"); restart = (q[0] << 8) | q[1]; }
         else if (m == 0xE0) { if (n >= 5 && memcmp(q, "JFIF\0", 5) == 0) jfif = true; }
         else if (m == 0xEE) { if (n >= 12 && memcmp(q, "Adobe\0", 6) == 0) adobe = q[11]; }
-        else if (m == 0xC0 || m == 0xC1) {                              // SOF0 / SOF1
+        else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {                 // SOF0 / SOF1 / SOF2 (progressive)
             if (haveFrame) fail(path + ": corrupt JPEG (two frame headers)");
             if (n < 6 || q[0] != 8) fail(path + ": only 8-bit JPEG is supported");
             H = (q[1] << 8) | q[2]; W = (q[3] << 8) | q[4];
@@ -535,10 +538,12 @@ Raw decodeJpeg(const std::string& d, const std::string& path)
                 c.x = (W * c.h + hmax - 1) / hmax; c.y = (H * c.v + vmax - 1) / vmax;            // samples that carry image data
                 c.w2 = mcux * c.h * 8; c.h2 = mcuy * c.v * 8;                                    // padded to whole MCUs
                 c.plane.assign((size_t)c.w2 * c.h2 + 15, 0);
+                if (m == 0xC2) c.coef.assign((size_t)(c.w2 / 8) * (c.h2 / 8) * 64, 0);
             }
+            progressive = (m == 0xC2);
             haveFrame = true;
-        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            fail(path + ": progressive / lossless / arithmetic-coded JPEG is not supported (baseline only)");
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            fail(path + ": lossless / hierarchical / arithmetic-coded JPEG is not supported (Huffman sequential and progressive only)");
         } else if (m == 0xDA) {                                         // SOS + entropy-coded data
             if (!haveFrame) fail(path + ": corrupt JPEG (scan before frame)");
             if (n < 1) fail(path + ": corrupt JPEG (SOS)");
@@ -549,8 +554,17 @@ Raw decodeJpeg(const std::string& d, const std::string& path)
                 int ci = -1; for (size_t c = 0; c < comp.size(); c++) if (comp[c].id == q[1 + 2 * k]) ci = (int)c;
                 if (ci < 0) fail(path + ": corrupt JPEG (scan component)");
                 comp[ci].td = q[2 + 2 * k] >> 4; comp[ci].ta = q[2 + 2 * k] & 15;
-                if (comp[ci].td > 3 || comp[ci].ta > 3 || !hdc[comp[ci].td].present || !hac[comp[ci].ta].present || !haveQ[comp[ci].tq]) fail(path + ": corrupt JPEG (missing table)");
+                if (comp[ci].td > 3 || comp[ci].ta > 3 || !haveQ[comp[ci].tq]) fail(path + ": corrupt JPEG (missing table)");
                 order[k] = ci;
+            }
+            const int Ss = q[1 + 2 * ns], Se = q[2 + 2 * ns], Ah = q[3 + 2 * ns] >> 4, Al = q[3 + 2 * ns] & 15;
+            if (progressive) {
+                if (Ss > 63 || Se > 63 || Ss > Se || Ah > 13 || Al > 13 || (Ss == 0 && Se != 0) || (Ss != 0 && ns != 1)) fail(path + ": corrupt JPEG (progressive scan parameters)");
+            } else if (Ss != 0 || Ah != 0 || Al != 0) fail(path + ": corrupt JPEG (scan parameters)");
+            for (int k = 0; k < ns; k++) {
+                const JpegComp& c = comp[order[k]];
+                if ((!progressive || Ss == 0) && !hdc[c.td].present) fail(path + ": corrupt JPEG (missing DC table)");
+                if ((!progressive || Ss != 0) && !hac[c.ta].present) fail(path + ": corrupt JPEG (missing AC table)");
             }
             JpegBits b{p, size, o + L};
             for (auto& c : comp) c.pred = 0;
@@ -572,21 +586,74 @@ Raw decodeJpeg(const std::string& d, const std::string& path)
                 }
                 jpegIdct(&c.plane[(size_t)c.w2 * by * 8 + (size_t)bx * 8], c.w2, blk);
             };
+            int eobrun = 0;
+            // one block of a progressive scan (T.81 G.1.2): DC first / refinement, AC first / refinement with end-of-band runs
+            auto blockProg = [&](JpegComp& c, int bx, int by) {
+                short* d = &c.coef[((size_t)by * (c.w2 / 8) + bx) * 64];
+                if (Ss == 0) {
+                    if (Ah == 0) {
+                        const int t = jpegDecodeSym(b, hdc[c.td], path);
+                        if (t > 15) fail(path + ": corrupt JPEG (DC size)");
+                        c.pred += jpegExtend(b.receive(t), t);
+                        d[0] = (short)(c.pred * (1 << Al));
+                    } else if (b.bit()) d[0] += (short)(1 << Al);
+                    return;
+                }
+                if (Ah == 0) {
+                    if (eobrun) { eobrun--; return; }
+                    int k = Ss;
+                    do {
+                        const int rs = jpegDecodeSym(b, hac[c.ta], path), r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r < 15) { eobrun = (1 << r); if (r) eobrun += b.receive(r); eobrun--; break; }
+                            k += 16;
+                        } else {
+                            k += r;
+                            if (k > 63) fail(path + ": corrupt JPEG (AC run)");
+                            d[kZigzag[k++]] = (short)(jpegExtend(b.receive(sz), sz) * (1 << Al));
+                        }
+                    } while (k <= Se);
+                    return;
+                }
+                const short bit = (short)(1 << Al);
+                auto refine = [&](short* p) { if (b.bit() && (*p & bit) == 0) { if (*p > 0) *p += bit; else *p -= bit; } };
+                if (eobrun) {
+                    eobrun--;
+                    for (int k = Ss; k <= Se; k++) { short* p = &d[kZigzag[k]]; if (*p != 0) refine(p); }
+                    return;
+                }
+                int k = Ss;
+                do {
+                    const int rs = jpegDecodeSym(b, hac[c.ta], path); int r = rs >> 4, sv = rs & 15;
+                    if (sv == 0) {
+                        if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += b.receive(r); r = 64; }    // end of band: only refinements follow in this block
+                    } else {
+                        if (sv != 1) fail(path + ": corrupt JPEG (refinement scan)");
+                        sv = b.bit() ? bit : -bit;
+                    }
+                    while (k <= Se) {                                   // skip r zero-history coefficients, refining the non-zero ones passed
+                        short* p = &d[kZigzag[k++]];
+                        if (*p != 0) refine(p);
+                        else { if (r == 0) { *p = (short)sv; break; } r--; }
+                    }
+                } while (k <= Se);
+            };
             auto mcuDone = [&]() -> bool {                              // false: the segment ended without the expected restart marker
                 if (--todo > 0) return true;
                 if (b.cnt < 24) b.fill();
                 if (!(b.marker >= 0xD0 && b.marker <= 0xD7)) return false;
-                b.reset(); for (auto& c : comp) c.pred = 0; todo = restart ? restart : 0x7fffffff;
+                b.reset(); for (auto& c : comp) c.pred = 0; todo = restart ? restart : 0x7fffffff; eobrun = 0;
                 return true;
             };
+            auto anyBlock = [&](JpegComp& c, int bx, int by) { if (progressive) blockProg(c, bx, by); else block(c, bx, by); };
             if (ns == 1) {                                              // non-interleaved: the component's own blocks in raster order
                 JpegComp& c = comp[order[0]];
                 const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3; bool go = true;
-                for (int j = 0; j < bh && go; j++) for (int i = 0; i < bw && go; i++) { block(c, i, j); go = mcuDone(); }
+                for (int j = 0; j < bh && go; j++) for (int i = 0; i < bw && go; i++) { anyBlock(c, i, j); go = mcuDone(); }
             } else {
                 const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax); bool go = true;
                 for (int j = 0; j < mcuy && go; j++) for (int i = 0; i < mcux && go; i++) {
-                    for (int k = 0; k < ns; k++) { JpegComp& c = comp[order[k]]; for (int y = 0; y < c.v; y++) for (int x = 0; x < c.h; x++) block(c, i * c.h + x, j * c.v + y); }
+                    for (int k = 0; k < ns; k++) { JpegComp& c = comp[order[k]]; for (int y = 0; y < c.v; y++) for (int x = 0; x < c.h; x++) anyBlock(c, i * c.h + x, j * c.v + y); }
                     go = mcuDone();
                 }
             }
@@ -601,6 +668,17 @@ Raw decodeJpeg(const std::string& d, const std::string& path)
         o += L;
     }
     if (!haveFrame || !decoded) fail(path + ": JPEG without image data");
+    if (progressive) {                                                  // all scans are in: dequantise (16-bit products) and transform the blocks that carry image data
+        for (auto& c : comp) {
+            if (!haveQ[c.tq]) fail(path + ": corrupt JPEG (missing quantisation table)");
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int j = 0; j < bh; j++) for (int i = 0; i < bw; i++) {
+                short* d = &c.coef[((size_t)j * (c.w2 / 8) + i) * 64];
+                for (int k = 0; k < 64; k++) d[k] = (short)(d[k] * quant[c.tq][k]);
+                jpegIdct(&c.plane[(size_t)c.w2 * j * 8 + (size_t)i * 8], c.w2, d);
+            }
+        }
+    }
     const int nc = (int)comp.size();
     int rgbIds = 0; if (nc == 3) { const char* tag = "RGB"; for (int k = 0; k < 3; k++) if (comp[k].id == tag[k]) rgbIds++; }
     const bool isRgb = nc == 3 && (rgbIds == 3 || (adobe == 0 && !jfif));

@@ -17,8 +17,8 @@ MeshCorners LoadObj(const std::string& path);
 
 // 8-bit image -> 0x00RRGGBB texels, top row first (Texture::LoadFromFile, template/texture.h:15-39).
 // Supported: PNG (8/16-bit, grey / RGB / palette, +alpha, interlaced or not), TGA (true-colour / grey, raw or RLE),
-// baseline JPEG (Huffman, 8 bit, grey / YCbCr / RGB, any sampling factors; decoded with stb_image's arithmetic so the texels are the
-// reference's), binary PPM (P6) / PGM (P5).
+// JPEG (Huffman sequential and progressive, 8 bit, grey / YCbCr / RGB, any sampling factors; decoded with stb_image's arithmetic so the
+// texels are the reference's), binary PPM (P6) / PGM (P5).
 struct Image { int width = 0, height = 0; std::vector<uint32_t> pixels; };
 Image LoadImage(const std::string& path);
 

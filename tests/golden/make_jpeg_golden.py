@@ -3,7 +3,7 @@
 synthetic test images and oracle/_ref — the reference's own lib/stb_image.h compiled in place — to decode them).
 
 The fixtures pin the host loader's baseline-JPEG decoder (cpu-ray-tracer_amd/csrc/host/loaders.cpp) to the texels the reference
-gets from stbi_load (template/texture.h:18): 4:4:4 / 4:2:2 / 4:2:0 sampling, greyscale, odd sizes, restart intervals, and the
+gets from stbi_load (template/texture.h:18): 4:4:4 / 4:2:2 / 4:2:0 sampling, greyscale, odd sizes, restart intervals, progressive scans, and the
 reference's own Wood_Tower_Col.jpg.  Fixtures are DATA (JPEG inputs made here + CRCs of the real stb decode)."""
 import io
 import json
@@ -50,7 +50,13 @@ def main():
              ("grey_50x33_q80", (50, 33), "L", dict(quality=80)),
              ("rgb420_restart_96x80_q70", (96, 80), "RGB", dict(quality=70, subsampling=2, restart_marker_blocks=3)),
              ("rgb444_restart_40x40_q30", (40, 40), "RGB", dict(quality=30, subsampling=0, restart_marker_rows=1)),
-             ("rgb420_optimized_64x48_q88", (64, 48), "RGB", dict(quality=88, subsampling=2, optimize=True))]
+             ("rgb420_optimized_64x48_q88", (64, 48), "RGB", dict(quality=88, subsampling=2, optimize=True)),
+             ("prog_rgb420_67x45_q85", (67, 45), "RGB", dict(quality=85, subsampling=2, progressive=True)),
+             ("prog_rgb444_40x56_q92", (40, 56), "RGB", dict(quality=92, subsampling=0, progressive=True)),
+             ("prog_rgb422_33x17_q40", (33, 17), "RGB", dict(quality=40, subsampling=1, progressive=True)),
+             ("prog_grey_50x33_q80", (50, 33), "L", dict(quality=80, progressive=True)),
+             ("prog_rgb420_restart_96x80_q70", (96, 80), "RGB", dict(quality=70, subsampling=2, progressive=True, restart_marker_blocks=2)),
+             ("prog_rgb420_8x8_q10", (8, 8), "RGB", dict(quality=10, subsampling=2, progressive=True))]
     for i, (name, (w, h), mode, kw) in enumerate(cases):
         px = picture(w, h, 100 + i)
         im = Image.fromarray(px if mode == "RGB" else px[:, :, 0], mode)
@@ -58,8 +64,8 @@ def main():
         im.save(path, "JPEG", **kw)
         dec = ref.image_load(path)                       # the REAL stb_image
         out[name] = dict(shape=list(dec.shape), packed=crc(orc.pack_rgb(dec)))
-    # progressive file: the loader must refuse it with a message (stb would decode it; documented limit)
-    Image.fromarray(picture(32, 32, 7), "RGB").save(os.path.join(HERE, "jpeg", "progressive_32x32.jpg"), "JPEG", quality=80, progressive=True)
+    # 4-component (CMYK) file: the loader must refuse it with a message (stb would convert it; documented limit)
+    Image.fromarray(picture(32, 32, 7), "RGB").convert("CMYK").save(os.path.join(HERE, "jpeg", "cmyk_32x32.jpg"), "JPEG", quality=80)
     # the reference's own JPEG texture (BASELINE config 4)
     dec = ref.image_load("/root/reference/assets/textures/Wood_Tower_Col.jpg")
     out["Wood_Tower_Col"] = dict(shape=list(dec.shape), packed=crc(orc.pack_rgb(dec)))

@@ -107,10 +107,11 @@ def test_host_camera_and_textures_match_reference_golden(crt):
 
 
 def test_jpeg_loader_matches_stb_golden(crt):
-    """Baseline JPEG in the host loader: texels must be the ones the reference's stbi_load produces (template/texture.h:18).
+    """JPEG in the host loader (sequential and progressive): texels must be the ones the reference's stbi_load produces (template/texture.h:18).
     tests/golden/jpeg/*.jpg were decoded by the REAL lib/stb_image.h (oracle/_ref) when the fixtures were made
     (tests/golden/make_jpeg_golden.py): 4:4:4 / 4:2:2 / 4:2:0, greyscale, odd sizes down to 1x1, restart intervals, optimised
-    Huffman tables, and the reference's own Wood_Tower_Col.jpg (BASELINE config 4's texture)."""
+    Huffman tables, progressive files (spectral selection + successive approximation), and the reference's own Wood_Tower_Col.jpg
+    (BASELINE config 4's texture)."""
     import json, zlib
     G = json.load(open(os.path.join(REPO, "tests", "golden", "jpeg_golden.json")))
     for name, g in sorted(G.items()):
@@ -121,8 +122,8 @@ def test_jpeg_loader_matches_stb_golden(crt):
     # the stb-decoded PNG fixture of the same texture (tools/make_tower_texture.py) holds the same texels
     assert np.array_equal(crt.load_image(os.path.join(ASSETS, "textures", "Wood_Tower_Col.jpg")), crt.load_image(os.path.join(ASSETS, "textures", "Wood_Tower_Col.png")))
     with pytest.raises(crt.CrtError) as e:
-        crt.load_image(os.path.join(REPO, "tests", "golden", "jpeg", "progressive_32x32.jpg"))
-    assert "progressive" in str(e.value) and e.value.code == -6
+        crt.load_image(os.path.join(REPO, "tests", "golden", "jpeg", "cmyk_32x32.jpg"))
+    assert "component" in str(e.value) and e.value.code == -6
     bad = open(os.path.join(REPO, "tests", "golden", "jpeg", "rgb420_16x16_q50.jpg"), "rb").read()
     import tempfile
     with tempfile.TemporaryDirectory() as d:
