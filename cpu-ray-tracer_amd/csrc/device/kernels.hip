@@ -371,7 +371,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // lane only ever pays for its own ray's length, never for the longest ray in the wave.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef CRT_SHADE_BATCH
-#define CRT_SHADE_BATCH 24
+#define CRT_SHADE_BATCH 24          // lanes the SHADE phase waits for in a launch of few windows (latency matters: its heaviest tile ends it)
+#endif
+#ifndef CRT_SHADE_BATCH_JOB
+#define CRT_SHADE_BATCH_JOB 40      // ... and in a many-window job, where fuller SHADE runs buy throughput (measured: -2.7 % per window, +7 % latency)
 #endif
 #ifndef CRT_TRI_BATCH
 #define CRT_TRI_BATCH 1
@@ -415,6 +418,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 
     Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
     uint32_t trips = 0;
+    const int shadeBatch = windows >= 8u ? CRT_SHADE_BATCH_JOB : CRT_SHADE_BATCH;
 #ifdef CRT_STAMPS
     // diagnostic build (-DCRT_STAMPS): shader-clock time per phase of this wave; never compiled into the product
     unsigned long long stT[6] = {0, 0, 0, 0, 0, 0}; uint32_t stN[4] = {0, 0, 0, 0}; uint32_t stL[4] = {0, 0, 0, 0};
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
         if (nDone + nNode + nTri + nTlas == 0) break;
         if (COUNT) trips++;
         // a phase runs when enough lanes wait for it; when no phase reaches its batch size the most populated one runs
-        const bool bigNode = nNode >= CRT_NODE_BATCH, bigTri = nTri >= CRT_TRI_BATCH, bigShade = nDone >= CRT_SHADE_BATCH;
+        const bool bigNode = nNode >= CRT_NODE_BATCH, bigTri = nTri >= CRT_TRI_BATCH, bigShade = nDone >= shadeBatch;
         const bool none = !bigNode && !bigTri && !bigShade && nTlas == 0;
         const bool runTlas = nTlas > 0;
         const bool runNode = bigNode || (none && nNode > 0 && nNode >= nTri && nNode >= nDone);
@@ -601,13 +605,10 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
             bool gen = first;
             if (miss || stop) {
                 f3 L = miss ? c : ((depth >= sc.depthLimit) ? mk3(0, 0, 0) : mk3(24, 24, 22));   // GetLightColor, file_scene.cpp:164-167
-                {
-                    float F[15];
+                // most paths end at depth 0..2: a level is read (and multiplied) only when some lane of the wave is that deep
 #pragma unroll
-                    for (int k = 0; k < 15; k++) F[k] = fst[k * 64];              // all 15 reads issued together; levels >= depth are never used
-#pragma unroll
-                    for (int k = 4; k >= 0; k--) if (depth > k) L = mk3(F[3 * k], F[3 * k + 1], F[3 * k + 2]) * L;
-                }
+                for (int k = 4; k >= 0; k--)
+                    if (depth > k) L = mk3(fst[(3 * k) * 64], fst[(3 * k + 1) * 64], fst[(3 * k + 2) * 64]) * L;
 #if defined(CRT_DUP) && CRT_DUP == 8
                 { f3 L2 = lnd3(c); for (int k = 4; k >= 0; k--) if (depth > k) L2 = mk3(fst[(3 * k) * 64], fst[(3 * k + 1) * 64], fst[(3 * k + 2) * 64]) * L2; sink3(L2); }
 #endif
