@@ -13,7 +13,7 @@ def build(specs):
     for spec in specs:
         name, _, flags = spec.partition("=")
         out = os.path.join(VDIR, "libcrt_%s.so" % name)
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", out] + flags.split() + SRC + ["-lz"]
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Xarch_device", "-fno-slp-vectorize", "-shared", "-o", out] + flags.split() + SRC + ["-lz"]
         print(" ".join(cmd)); subprocess.check_call(cmd, cwd=PKG)
 
 def run(args):
