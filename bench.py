@@ -78,7 +78,12 @@ def cpu_baseline(scene_xml, kind, W, H, budget_s=15.0):
     o.render(frames, threads)
     dt = (time.perf_counter() - t1) + one
     c = o.counters()
-    return {"value": round(c["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+    # SURVEY 8(d) also asks for the single-thread figure: two more frames on one thread
+    o.reset_counters()
+    t2 = time.perf_counter()
+    o.render(2, 1)
+    one_thread = o.counters()["rays"] / (time.perf_counter() - t2) / 1e6
+    return {"value": round(c["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port", "value_1_thread": round(one_thread, 3),
             "sample": "%d frames (spp 2..%d) of the same %dx%d scene, %d threads (= usable host cores: affinity capped by the cgroup CPU quota), %.1f s" % (frames + 1, frames + 2, W, H, threads, dt),
             "ms_per_frame": round(dt / (frames + 1) * 1e3, 2)}
 
