@@ -51,7 +51,7 @@ def algorithmic_bytes(c):
     return 64 * c["interior_iters"] + 40 * c["tri_tests"] + 64 * c["blas_visits"] + 76 * c["mesh_hits"] + 32 * c["primary"]
 
 
-def cpu_baseline(scene_xml, kind, W, H, budget_s=15.0):
+def cpu_baseline(scene_xml, kind, W, H, budget_s=float(os.environ.get("CRT_BENCH_CPU_BUDGET_S", "15"))):
     """Times the CPU oracle (kind "port": the repo's restatement of the reference algorithm) on this box's cores."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import orc

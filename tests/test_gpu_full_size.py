@@ -163,3 +163,27 @@ def test_config4_tower_1080p_256spp(crt, orc):
         o.render(S, 1)
         x0, y0 = (t % tw) * 16, (t // tw) * 16
         assert np.array_equal(acc[y0:y0 + 16, x0:x0 + 16], o.accumulator()[y0:y0 + 16, x0:x0 + 16]), t
+
+
+def test_bench_json_contract():
+    """bench.py's one-line JSON: the driver's contract fields + the roofline and cpu_baseline objects (small run of the real script)"""
+    import json, os, subprocess, sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--width", "320", "--height", "192"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, CRT_BENCH_CPU_BUDGET_S="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k, t in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)]:
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "Mrays/s" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert rf["traffic"] is None            # the PMC figure is attached only to the workload it was collected on
+    assert rf["launches"] == 2 and rf["achieved"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and "sample" in cb
+    assert d["value"] > 20 * cb["value"]
