@@ -35,6 +35,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 REPO = os.path.dirname(os.path.abspath(__file__))
 ASSETS = os.path.join(REPO, "assets")
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+VALU_ISSUE_PEAK_GINSTR = 1050.0   # measured fp32 VALU issue peak of the chip, G wave-instructions/s (tools/microbench/valu_peak.hip, profiles/r01_valu_peak.txt)
 
 
 def load_crt():
@@ -212,6 +213,7 @@ def main():
     alg_bytes_launch = algorithmic_bytes(counts) * (args.steps + args.warmup) / max(all_launches, 1)
     achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     job_launch_ms = kernel_ms / max(launches, 1)
+    valu_instrs = None
     traffic = None          # HBM bytes of the job's launch from the PMC passes (tools/collect_profiles.sh), only for the workload they were collected on
     pmc_path = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(pmc_path):
@@ -219,6 +221,7 @@ def main():
             t = json.load(open(pmc_path))
             if t.get("workload") == [args.scene, args.kind, W, H, SPP, args.steps]:
                 traffic = t.get("render_tiles_kernel_bytes_per_launch")
+                valu_instrs = t.get("render_tiles_kernel_valu_wave_instructions_per_launch")
         except Exception:
             traffic = None
     out = {
@@ -247,6 +250,10 @@ def main():
                      "job_launch_achieved": round(algorithmic_bytes(counts) / max(launches_per_step, 1e-9) / (job_launch_ms * 1e-3) / 1e9, 2) if job_launch_ms > 0 else None,
                      "job_achieved": round(rays / elapsed * (algorithmic_bytes(counts) / max(counts["rays"], 1)) / 1e9, 2),
                      "accumulate_kernel_ms_per_step": round(acc_ms / args.steps, 4),
+                     "valu_issue": None if not valu_instrs or job_launch_ms <= 0 else {
+                         "wave_instructions_per_job_launch": valu_instrs, "achieved_ginstr_s": round(valu_instrs / (job_launch_ms * 1e-3) / 1e9, 1),
+                         "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "frac": round(valu_instrs / (job_launch_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GINSTR, 4),
+                         "note": "the limiter in practice: SQ_INSTS_VALU of the job's launch (PMC pass) / its duration, against the chip's measured fp32 VALU issue peak"},
                      "counters_per_step": {k: round(v) for k, v in counts.items()},
                      "note": "achieved = mean algorithmic bytes per render_tiles_kernel launch / mean launch duration over all its launches in this process (warm-up job + timed job; HIP events on the launch stream) = the average rocprofv3 --stats reports; job_launch_* = the timed job's launch alone; job_achieved = algorithmic GB/s over the whole timed region incl. the ordered accumulate; the bytes are algorithmic (SURVEY 8(d)) and mostly served by L2 — traffic = HBM bytes of the job's launch from the PMC passes"},
     }

@@ -46,6 +46,9 @@ if rk and "FETCH_SIZE" in pmc[rk[0]] and "WRITE_SIZE" in pmc[rk[0]]:
     if "TCC_HIT_sum" in pmc[rk[0]]:
         h, m = pmc[rk[0]]["TCC_HIT_sum"]["max_dispatch"], pmc[rk[0]]["TCC_MISS_sum"]["max_dispatch"]
         out["l2_hit_rate"] = h / (h + m)
+    if "SQ_INSTS_VALU" in pmc[rk[0]]:
+        out["render_tiles_kernel_valu_wave_instructions_per_launch"] = int(pmc[rk[0]]["SQ_INSTS_VALU"]["max_dispatch"])
+        out["render_tiles_kernel_salu_wave_instructions_per_launch"] = int(pmc[rk[0]]["SQ_INSTS_SALU"]["max_dispatch"])
     ak = [k for k in pmc if "accumulate_kernel" in k]
     if ak and "FETCH_SIZE" in pmc[ak[0]]:
         out["accumulate_kernel_fetch_bytes_x2"] = int(2 * pmc[ak[0]]["FETCH_SIZE"]["max_dispatch"] * 1024)   # wide coalesced streaming reads: the guide's x2 correction applies
