@@ -461,13 +461,15 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
         // state ballots: the compares write their lane masks straight into scalar registers; `liveMask` (maintained below) removes
         // finished lanes with one scalar AND instead of a per-lane predicate round trip
         const uint64_t mDone = __builtin_amdgcn_ballot_w64(cur == kRefDone) & liveMask;
-        const uint64_t mNode = __builtin_amdgcn_ballot_w64((cur & 0xC0000000u) == kRefInterior) & liveMask;
+        // (two-level scenes: a TLAS interior node is walked by the NODE phase too — its two child TlasNodes arrive in q0..q3 in the NodePair
+        // layout {lo, ref, hi, -} x 2, and the ordered descend / push / pop is the same code; only TLAS leaves need the TLAS phase)
+        const uint64_t mNode = __builtin_amdgcn_ballot_w64(KIND == 1 ? (((cur >> 31) ^ (cur >> 30)) & 1u) != 0u : (cur & 0xC0000000u) == kRefInterior) & liveMask;
         const uint64_t mTri = __builtin_amdgcn_ballot_w64(cur != kRefDone && (cur & 0xC0000000u) == 0u) & liveMask;
-        const uint64_t mTlas = (KIND == 1) ? (__builtin_amdgcn_ballot_w64((cur & kRefTlasBit) != 0u) & liveMask) : 0ull;
+        const uint64_t mTlas = (KIND == 1) ? (__builtin_amdgcn_ballot_w64((cur & 0xC0000000u) == kRefTlasLeaf) & liveMask) : 0ull;
         const bool isDone = live && cur == kRefDone;
-        const bool isNode = live && (cur & 0xC0000000u) == kRefInterior;
+        const bool isNode = live && (KIND == 1 ? (((cur >> 31) ^ (cur >> 30)) & 1u) != 0u : (cur & 0xC0000000u) == kRefInterior);
         const bool isTri = live && cur != kRefDone && (cur & 0xC0000000u) == 0u;
-        const bool isTlas = (KIND == 1) && live && (cur & kRefTlasBit) != 0u;
+        const bool isTlas = (KIND == 1) && live && (cur & 0xC0000000u) == kRefTlasLeaf;
         const int nDone = __popcll(mDone), nNode = __popcll(mNode), nTri = __popcll(mTri);
         const int nTlas = (KIND == 1) ? __popcll(mTlas) : 0;
         if (nDone + nNode + nTri + nTlas == 0) break;
@@ -689,27 +691,13 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
         CRT_STAMP(s2); stT[1] += s2 - s1;
 #endif
         if (KIND == 1 && runTlas && isTlas) {
-            // ---------------- TLAS phase (infra/tlas_bvh.cpp:83-111) -------------------------------------------------
-            if (COUNT) cn.tlas++;
-            uint32_t next;
-            if ((cur & kRefInterior) != 0u) {
-                // TLAS leaf: enter the BLAS (BLASBVH::Intersect, blas_bvh.cpp:376-381): object-space ray through the
-                // pre-loaded invT rows, return marker on the stack, BLAS root
-                if (COUNT) cn.visits++;
-                to_object_space(q0, q1, q2, O, D, tO, tD, trD);
-                rayFinite = finite3(trD);
-                stk[sp * 64u] = kRefReturn; sp++;
-                next = asu(q3.z);                                                 // Instance::rootRef
-            } else {
-                const uint32_t top = CRT_TOP();
-                float d1 = box_exact(q0, q1, tO, trD, h.t), d2 = box_exact(q2, q3, tO, trD, h.t);
-                uint32_t r1 = asu(q0.w), r2 = asu(q2.w);
-                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
-                stk[sp * 64u] = r2;
-                const bool hitN = d1 != 1e30f, push = hitN && d2 != 1e30f, pop = !hitN && sp != 0u;
-                next = hitN ? r1 : (pop ? top : kRefDone);
-                sp = sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
-            }
+            // ---------------- TLAS phase: a TLAS leaf (infra/tlas_bvh.cpp:91-95) -> enter the BLAS (BLASBVH::Intersect, blas_bvh.cpp:376-381):
+            // object-space ray through the pre-loaded invT rows, return marker on the stack, BLAS root
+            if (COUNT) { cn.tlas++; cn.visits++; }
+            to_object_space(q0, q1, q2, O, D, tO, tD, trD);
+            rayFinite = finite3(trD);
+            stk[sp * 64u] = kRefReturn; sp++;
+            const uint32_t next = asu(q3.z);                                      // Instance::rootRef
             if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
             cur = next;
         }
@@ -720,7 +708,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
             // ---------------- NODE phase (infra/bvh.cpp:244-257) -------------------------------------------------
             const bool allFinite = __builtin_amdgcn_ballot_w64(isNode && !rayFinite) == 0ull;
             if (isNode) {
-                if (COUNT) cn.interior++;
+                if (COUNT) { if (KIND == 1 && (cur & kRefTlasBit) != 0u) cn.tlas++; else cn.interior++; }
                 uint32_t top = CRT_TOP();                                            // speculative: lands during the slab arithmetic
                 float d1, d2;
                 if (allFinite) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
