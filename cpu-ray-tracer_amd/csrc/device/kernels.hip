@@ -363,8 +363,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 //                             plane, first traversal step from the root's child pair in the kernel arguments)
 //     BVH interior         -> NODE phase: two slab tests on the pre-loaded NodePair, ordered descend / push / pop
 //     BVH leaf             -> TRI phase: ONE Möller–Trumbore test on the pre-loaded LeafTri, next triangle or pop
-//     TLAS interior / leaf -> TLAS phase (two-level scenes): two slab tests on the pre-loaded child nodes / enter the
-//                             BLAS through the pre-loaded invT rows
+//     TLAS interior        -> NODE phase as well (two-level scenes): its two child TlasNodes are fetched into the NodePair layout
+//     TLAS leaf            -> TLAS phase: enter the BLAS through the pre-loaded invT rows (return marker on the stack)
 // One trip of the wave's loop = ballot the states, run each phase that has enough lanes (thresholds below: SHADE waits
 // for 24 lanes unless nothing else can run, the others run whenever populated), then issue the record loads: four 16-byte loads at
 // `geom + 32-bit offset`.  The loads fly while the next trip's ballots and the other phases' arithmetic execute, and a
