@@ -139,6 +139,14 @@ __device__ __forceinline__ float rnd(uint32_t& s)
     s ^= s << 13; s ^= s >> 17; s ^= s << 5;
     return (float)s * 2.3283064365387e-10f;
 }
+// RandomFloat(seed) * 2 - 1 (diffusereflection, tmplmath.h:540) in one rounding: 2.3283064365387e-10f is exactly 2^-32 as a float, so the
+// scaling of the converted integer and the doubling are both exact and the only rounding is the final subtraction — fma((float)s, 2^-31, -1)
+// is that same single rounding of the same real number
+__device__ __forceinline__ float rnd_pm1(uint32_t& s)
+{
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+    return __builtin_fmaf((float)s, 4.656612873077392578125e-10f, -1.0f);
+}
 
 
 struct Hit { float t, u, v; int objIdx, triIdx; };
@@ -588,9 +596,9 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                 } else {                                                          // diffuse, renderer.cpp:93-99; diffusereflection tmplmath.h:535-544
                     f3 Rr;
                     do {
-                        const float rz = __builtin_fmaf(rnd(seed), 2.0f, -1.0f);   // draw order pinned z, y, x; r*2 is exact,
-                        const float ry = __builtin_fmaf(rnd(seed), 2.0f, -1.0f);   // so the fused form rounds once exactly like r*2-1
-                        const float rx = __builtin_fmaf(rnd(seed), 2.0f, -1.0f);
+                        const float rz = rnd_pm1(seed);                           // draw order pinned z, y, x
+                        const float ry = rnd_pm1(seed);
+                        const float rx = rnd_pm1(seed);
                         Rr = mk3(rx, ry, rz);
                     } while (dot3(Rr, Rr) > 1);
 #if defined(CRT_DUP) && CRT_DUP == 7
