@@ -207,6 +207,7 @@ void crt_destroy(crt_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
+    for (auto st : c->streams) (void)hipStreamSynchronize(st);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->freeScene();
     for (auto& ev : c->evPool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -382,6 +383,9 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         bindTex(m, sd->materials[i].texture);
     }
 
+    // launches still in flight read the previous scene's buffers (render streams first: the main stream's accumulates wait on them)
+    for (auto st : c->streams) HIPCK(c, hipStreamSynchronize(st));
+    HIPCK(c, hipStreamSynchronize(c->stream));
     c->freeScene();
     uint32_t* dTexels = nullptr;
     HIPCK(c, hipMalloc((void**)&dTexels, (size_t)texels * 4)); c->sceneAllocs.push_back(dTexels);

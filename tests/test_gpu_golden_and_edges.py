@@ -327,6 +327,28 @@ def test_sample_pool_ring_wraps_with_mixed_launch_sizes(crt, orc):
     assert ctx.counters()["rays"] == o.counters()["rays"]
 
 
+def test_scene_reupload_and_destroy_with_renders_in_flight(crt, orc):
+    """crt_upload_scene / crt_destroy while asynchronous launches still read the previous scene's device buffers: both wait for them"""
+    a = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    b = crt.HostScene(scene_path("cube_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(256, 160)
+    a.upload(ctx)
+    ctx.render(1, 64, 1)            # in flight ...
+    b.upload(ctx)                   # ... while the scene is replaced
+    first = ctx.accumulator()
+    ctx.clear(); ctx.render(1, 2, 1)
+    o, _ = orc.load_scene(scene_path("cube_scene.xml"), 0, ASSETS)
+    o.renderer_init(256, 160)
+    o.render(2, 4)
+    assert np.array_equal(ctx.accumulator(), o.accumulator())
+    o2, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o2.renderer_init(256, 160)
+    o2.set_tile_range(37, 1); o2.render(64, 4)
+    assert np.array_equal(first[32:48, 80:96], o2.accumulator()[32:48, 80:96])     # tile 37 = (tx 5, ty 2) of the bunny render finished intact
+    ctx.render(3, 640, 1)
+    ctx.close()                     # destroy with a long launch in flight
+
+
 @pytest.mark.parametrize("streams", [1, 3, 7])
 def test_back_to_back_renders_keep_frame_order(crt, orc, streams):
     """many asynchronous crt_render calls (they overlap on `streams` HIP streams) must accumulate in frame order:
