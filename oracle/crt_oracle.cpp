@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -1040,33 +1041,64 @@ int orc_set_spp(orc_ctx* c, int spp) { c->spp = spp; return 0; }
 int orc_get_spp(orc_ctx* c) { return c->spp; }
 int orc_set_tile_range(orc_ctx* c, int first, int count) { c->tileFirst = first; c->tileCount = count; return 0; }
 
-int orc_tick(orc_ctx* c, int nThreads) // renderer.cpp:144-168
+// One Tick (renderer.cpp:144-168) over the tiles [first, last), tiles handed out dynamically to `nThreads` workers.  Every worker keeps its
+// counters and the tile's energy sum in locals (its own cache lines) and publishes them once per tile / once per frame: neighbouring
+// entries of a shared array written on every traversal step would bounce between the cores' caches and serialise the workers.
+namespace {
+struct FramePool {                                   // persistent workers for a run of frames: one spawn / join per orc_render, not per Tick
+    orc_ctx* c; int nThreads, frames, tw, first, last;
+    std::atomic<int> next{0}, arrived{0}, generation{0};
+    std::vector<float> sums;
+    std::mutex mu;
+    void frame_begin() { std::fill(sums.begin(), sums.end(), 0.0f); c->tileSeedOut.assign(sums.size(), 0u); c->tileSeedSpp = c->spp; next.store(first); }
+    void frame_end() { c->energy = 0; for (float s : sums) c->energy += s; c->spp += c->passes; }
+    void barrier(bool leaderWork)                    // sense-reversing spin barrier; the last arrival closes the frame and opens the next
+    {
+        const int gen = generation.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nThreads) {
+            if (leaderWork) { frame_end(); if (--frames > 0) frame_begin(); }
+            arrived.store(0, std::memory_order_relaxed);
+            generation.store(gen + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (generation.load(std::memory_order_acquire) == gen) { if (++spins > 2000) std::this_thread::yield(); }
+        }
+    }
+    void worker()
+    {
+        Counters cn;
+        for (;;) {
+            for (;;) {
+                const int i = next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= last) break;
+                float sum = 0.0f; uint32_t seedOut = 0;
+                c->process_tile(i % tw, i / tw, sum, cn, &seedOut);
+                sums[i] = sum; c->tileSeedOut[i] = seedOut;
+            }
+            barrier(true);
+            if (frames <= 0) break;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        c->counters.add(cn);
+    }
+};
+} // namespace
+
+int orc_render(orc_ctx* c, int frames, int nThreads)
 {
     if (!c->built || c->W == 0) { c->err = "scene not built or renderer not initialised"; return -1; }
+    if (frames <= 0) return 0;
     const int tw = c->W / 16, th = c->H / 16, tiles = tw * th;     // truncating division: trailing rows/cols stay untouched
-    int first = 0, last = tiles;
-    if (c->tileCount >= 0) { first = c->tileFirst; last = std::min(tiles, c->tileFirst + c->tileCount); }
-    std::vector<float> sums(tiles, 0.0f);
-    c->tileSeedOut.assign(tiles, 0u); c->tileSeedSpp = c->spp;
-    if (nThreads < 1) nThreads = 1;
-    std::atomic<int> next(first);
-    std::vector<Counters> cns(nThreads);
-    auto worker = [&](int tid) {
-        for (;;) {
-            int i = next.fetch_add(1);
-            if (i >= last) break;
-            c->process_tile(i % tw, i / tw, sums[i], cns[tid], &c->tileSeedOut[i]);
-        }
-    };
-    if (nThreads == 1) worker(0);
-    else { std::vector<std::thread> th_; for (int t = 0; t < nThreads; t++) th_.emplace_back(worker, t); for (auto& t : th_) t.join(); }
-    for (auto& cn : cns) c->counters.add(cn);
-    c->energy = 0;
-    for (int i = 0; i < tiles; i++) c->energy += sums[i];
-    c->spp += c->passes;
+    FramePool p; p.c = c; p.nThreads = nThreads < 1 ? 1 : nThreads; p.frames = frames; p.tw = tw;
+    p.first = 0; p.last = tiles;
+    if (c->tileCount >= 0) { p.first = c->tileFirst; p.last = std::min(tiles, c->tileFirst + c->tileCount); }
+    p.sums.assign(tiles, 0.0f);
+    p.frame_begin();
+    if (p.nThreads == 1) p.worker();
+    else { std::vector<std::thread> th_; for (int t = 0; t < p.nThreads; t++) th_.emplace_back([&p] { p.worker(); }); for (auto& t : th_) t.join(); }
     return 0;
 }
-int orc_render(orc_ctx* c, int frames, int nThreads) { for (int f = 0; f < frames; f++) { int r = orc_tick(c, nThreads); if (r) return r; } return 0; }
+int orc_tick(orc_ctx* c, int nThreads) { return orc_render(c, 1, nThreads); }
 const float* orc_accumulator(orc_ctx* c) { return c->acc.data(); }
 const uint32_t* orc_screen(orc_ctx* c) { return c->screen.data(); }
 float orc_energy(orc_ctx* c) { return c->energy; }
