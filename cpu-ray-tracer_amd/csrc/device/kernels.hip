@@ -361,8 +361,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 
 // ------------------------------------------------------------------------------------------------------------
 // render_tiles_kernel<KIND, COUNT>: grid = (tiles owned by this ctx) x (64-frame windows of the launch), block = one wavefront (lane = frame).
-// slab layout: float4 [window][tileLocal][sample 0..S)[pixel 0..255], S = frames*passes of the window, sample = frame*passes + pass
-// (sample-major inside a tile: accumulate_kernel's 256 threads read 4 KB rows; the stores here are scattered either way)
+// slab layout: float4 [window][tileLocal][pixel 0..255][sample 0..64*passes), sample = frame*passes + pass (a partial last window leaves the
+// tail of its rows unused).  Pixel-major: the lanes of a wave are the consecutive samples of a pixel, so lanes that finish the same pixel
+// write neighbouring 16-byte pieces of one row and the L2 merges them into whole lines before they leave for HBM; accumulate_kernel
+// transposes through LDS on the read side.
 //
 // Per-lane traversal state is ONE packed reference `cur` (layout.h), the 64-byte record it names — already
 // PRE-LOADED into registers q0..q3 by the trip that produced it — and a stack in a per-lane LDS column:
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 #endif
                 uint32_t pix = item, pass = 0;
                 if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
-                slab[((size_t)tl * S + (lane * passes + pass)) * 256u + pix] = make_float4(L.x, L.y, L.z, 0.0f);
+                slab[((size_t)tl * 256u + pix) * (64u * passes) + (lane * passes + pass)] = make_float4(L.x, L.y, L.z, 0.0f);
                 item++;
                 gen = true;
                 if (item >= items) { live = false; gen = false; }
@@ -806,34 +808,60 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 
 // ------------------------------------------------------------------------------------------------------------
 // accumulate_kernel: accumulator[pixel] += the slab's samples in (window, frame, pass) order — the reference's
-// `accumulator[..] +=` order, renderer.cpp:124.  One 256-thread block per owned tile, one thread per pixel; every step of
-// the loop reads one 4 KB row of the slab (256 consecutive float4), so the kernel streams at HBM rate.  The adds of a pixel
-// stay in one thread, in order; eight loads are kept in flight ahead of them.
+// `accumulator[..] +=` order, renderer.cpp:124.  The slab is pixel-major ([tile][pixel][sample]); this kernel streams it with
+// fully coalesced 1 KB loads and transposes through LDS:
+//   block = one owned tile, 4 wavefronts; wavefront w owns the tile's image rows 4w .. 4w+3 (16 pixels each) and never talks to the others;
+//   per (row, window, block of 64 samples): lane l fetches sample l of each of the row's 16 pixels (16 loads of 1 KB per wave in flight),
+//   parks them in the wave's LDS region, then lane (pixel j = l / 4, channel = l % 4) adds its 64 values IN ORDER to its running sum.
+// The running sums of a row are 64 consecutive floats of the accumulator (one 256-byte line).  Every addition of a channel happens
+// in one lane, in frame order; no float atomics anywhere.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ slab, float4* __restrict__ acc,
+constexpr uint32_t kAccRowF4 = 65u;                  // float4 per pixel row in LDS: 64 samples + 1 pad (bank spread for the channel-wise reads)
+constexpr uint32_t kAccWaveLds = 16u * kAccRowF4 * 16u;   // bytes per wavefront
+__global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restrict__ slab, float* __restrict__ acc,
                                                           uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                           uint32_t W, uint32_t frames, uint32_t passes)
 {
-    const uint32_t tl = blockIdx.x, pix = threadIdx.x;
+    extern __shared__ float4 accLds[];
+    const uint32_t tl = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (tl >= tileCount) return;
     const uint32_t tile = tileFirst + tl * tileStride;
-    const uint32_t x = (tile % tilesX) * 16u + (pix & 15u), y = (tile / tilesX) * 16u + (pix >> 4);
-    const size_t winStride = (size_t)tileCount * 256u * 64u * passes;
-    float4 a = acc[x + (size_t)y * W];
-    for (uint32_t f0 = 0; f0 < frames; f0 += 64u, slab += winStride) {
-        const uint32_t S = ((frames - f0 < 64u) ? frames - f0 : 64u) * passes;
-        const float4* __restrict__ s = slab + (size_t)tl * S * 256u + pix;
-        uint32_t i = 0;
-        for (; i + 8u <= S; i += 8u) {
-            float4 v[8];
+    const uint32_t x0 = (tile % tilesX) * 16u, y0 = (tile / tilesX) * 16u;
+    const uint32_t rowLen = 64u * passes;                                      // float4 per pixel row of the slab
+    const size_t winStride = (size_t)tileCount * 256u * rowLen;
+    float4* my4 = accLds + wave * (16u * kAccRowF4);
+    const float* myF = reinterpret_cast<const float*>(my4) + (lane >> 2) * (kAccRowF4 * 4u) + (lane & 3u);
+    for (uint32_t r = 0; r < 4u; r++) {
+        const uint32_t v = wave * 4u + r;                                      // row of the tile
+        float* __restrict__ ap = acc + ((size_t)(x0 + (size_t)(y0 + v) * W)) * 4u + lane;   // 16 pixels x 4 channels = 64 consecutive floats
+        float a = *ap;
+        const float4* __restrict__ rowBase = slab + ((size_t)tl * 256u + v * 16u) * rowLen;
+        for (uint32_t f0 = 0; f0 < frames; f0 += 64u, rowBase += winStride) {
+            const uint32_t S = ((frames - f0 < 64u) ? frames - f0 : 64u) * passes;   // valid samples of this window's rows
+            for (uint32_t b = 0; b < S; b += 64u) {
+                const uint32_t n = (S - b < 64u) ? S - b : 64u;
+                float4 t[16];
+                if (lane < n) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = s[(size_t)(i + k) * 256u];
+                    for (int j = 0; j < 16; j++) t[j] = rowBase[(size_t)j * rowLen + b + lane];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+                    for (int j = 0; j < 16; j++) my4[j * kAccRowF4 + lane] = t[j];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // wave-private region: LDS executes a wave's operations in order
+                uint32_t s = 0;
+                for (; s + 8u <= n; s += 8u) {
+                    float x[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) x[k] = myF[(s + k) * 4u];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) a += x[k];
+                }
+                for (; s < n; s++) a += myF[s * 4u];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         }
-        for (; i < S; i++) { const float4 v = s[(size_t)i * 256u]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        *ap = a;
     }
-    acc[x + (size_t)y * W] = a;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1123,7 +1151,7 @@ extern "C" hipError_t crt_launch_accumulate(const void* slab, void* acc, uint32_
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
     dim3 grid(tileCount), block(256);
-    hipLaunchKernelGGL(crt::accumulate_kernel, grid, block, 0, stream, (const float4*)slab, (float4*)acc, tileFirst, tileStride, tileCount, tilesX, W, frames, passes);
+    hipLaunchKernelGGL(crt::accumulate_kernel, grid, block, 4u * crt::kAccWaveLds, stream, (const float4*)slab, (float*)acc, tileFirst, tileStride, tileCount, tilesX, W, frames, passes);
     return hipGetLastError();
 }
 
