@@ -17,6 +17,7 @@
 #include <vector>
 
 extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_whitted(const crt::Scene*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
@@ -62,6 +63,7 @@ struct crt_ctx {
     float meshLo[3] = {0, 0, 0}, meshHi[3] = {0, 0, 0}; bool orderDirty = true;
     uint32_t* dTileOrder = nullptr;
     bool haveScene = false;
+    bool usePool = true;          // render_pool_kernel (stream pool); CRT_RENDER_KERNEL=tiles selects render_tiles_kernel (one stream per lane)
     uint32_t ldsBytes = 0;
     // timing of the last crt_render
     std::vector<EventPair> evPool; size_t evUsedRender = 0, evUsedAcc = 0;
@@ -153,6 +155,7 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     if (cfg->device < 0 || cfg->device >= ndev) { g_createError = "crt_create: device ordinal out of range"; return CRT_ERR_INVALID; }
     crt_ctx* c = new crt_ctx();
     c->cfg = *cfg;
+    if (const char* k = getenv("CRT_RENDER_KERNEL")) c->usePool = strcmp(k, "tiles") != 0;
     if (c->cfg.depthLimit < 0) c->cfg.depthLimit = 5;
     if (c->cfg.depthLimit > 5) { g_createError = "crt_create: depthLimit > 5 unsupported (throughput stack holds 5 factors; reference default is 5)"; delete c; return CRT_ERR_UNSUPPORTED; }
     if (c->cfg.maxFramesPerLaunch <= 0) c->cfg.maxFramesPerLaunch = 4096;                     // 64 windows of 64 frames
@@ -618,7 +621,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         EventPair ev;
         if ((r = take_event(c, c->evRender, &ev))) return r;
         HIPCK(c, hipEventRecord(ev.a, st));
-        HIPCK(c, crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+        HIPCK(c, (c->usePool ? crt_launch_render_pool : crt_launch_render)(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
                                    spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, st));
         HIPCK(c, hipEventRecord(ev.b, st));
         // ordered accumulation on the main stream (frame order = launch order), behind this launch

@@ -1,0 +1,475 @@
+// render_pool.hip — render_pool_kernel: the path tracer's per-tile sample loop ("3. PathTracer/renderer.cpp":117-131, Sample :50-100,
+// FindNearest infra/scene/file_scene.cpp:170-175 / tlas_file_scene.cpp:201-206, IntersectBVH infra/bvh.cpp:224-258) as a STREAM POOL.
+//
+// The unit of work is the reference's RNG stream: one xorshift32 stream per (tile, frame), consumed serially over the tile's 256
+// pixels (renderer.cpp:120-126).  A wavefront owns S > 64 such streams of one tile (S consecutive frames) but has only 64 lanes, and
+// a stream is not tied to a lane:
+//   * a stream that is WALKING the acceleration structure is resident in a lane: its ray, nearest hit, node reference and
+//     pre-loaded node / triangle record live in that lane's registers, its traversal stack in the lane's LDS column;
+//   * a stream that WAITS for shading is parked in LDS (ray, hit, RNG state, pixel counter, the path's throughput factors —
+//     33 dwords) and queued by what it needs next: the END queue (the path ended: sky lookup or light / depth limit, unwind the
+//     throughput factors, store the sample, generate the next pixel's primary ray) or the BOUNCE queue (surface hit: normal,
+//     uv, albedo, mirror / dielectric / rejection-sampled diffuse direction);
+//   * a shading pass takes up to 64 streams from ONE queue — all lanes run the same branch of Renderer::Sample — starts each
+//     stream's next FindNearest (light quad, floor plane, the root step from the kernel arguments) and queues the stream as
+//     READY to walk, or, when the ray misses both root children, straight back into a shading queue;
+//   * lanes whose stream finished walking take the next READY stream.
+// So the traversal phases run on lanes that are (nearly) all walking and the shading passes on (nearly) full wavefronts, instead
+// of every phase running on the sub-set of 64 fixed streams that happens to be in that state (render_tiles_kernel).  Per stream
+// nothing changes: every ray visits the reference's nodes in the reference's order and every float expression is evaluated as
+// written there, so the image is bit-identical to render_tiles_kernel's and to the CPU oracle's.
+//
+// Numerics: -ffp-contract=off, IEEE + - * / sqrt only (dev_common.h).  No MFMA: pointer chasing + slab / Möller–Trumbore tests.
+#include "dev_common.h"
+
+namespace crt {
+
+// parked stream state, SoA in LDS: field f of stream s at st[f * S + s]
+enum : uint32_t {
+    F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_RX, F_RY, F_RZ,   // ray origin, direction, reciprocal direction (world space)
+    F_T, F_U, F_V, F_OBJ, F_TRI,                                 // nearest hit: FindNearest's result once the walk is over
+    F_SEED, F_META,                                              // RNG state; item | depth << 11 | inside << 14 | fresh << 15
+    F_CUR, F_PEND,                                               // READY streams: node reference to start at, far root child to push (0 = none)
+    F_FAC,                                                       // 15 throughput factors: component j of depth k at F_FAC + 3k + j
+    F_COUNT = F_FAC + 15
+};
+constexpr uint32_t kMetaItemMask = 0x7ffu, kMetaDepthShift = 11u, kMetaInside = 1u << 14, kMetaFresh = 1u << 15;
+constexpr uint32_t kQueueMask = 127u;                            // queues are rings of 128 one-byte stream ids (S <= 128)
+
+#ifndef CRT_POOL_SHADE_MIN
+#define CRT_POOL_SHADE_MIN 64     // streams a shading pass waits for ...
+#endif
+#ifndef CRT_POOL_STARVE
+#define CRT_POOL_STARVE 40        // ... unless fewer than this many streams are walking or ready to walk
+#endif
+
+template <int KIND, bool COUNT, int S>
+__global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, Counters* __restrict__ counters,
+                                                             unsigned long long* __restrict__ tileClocks, const uint32_t* __restrict__ tileOrder,
+                                                             uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
+                                                             uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t groups)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long clk0 = COUNT ? wall_clock64() : 0ull;
+    // block -> (tile rank, group of S frames), rank-major: all groups of the expensive tiles (listed first by the host) are dispatched first
+    const uint32_t rank = blockIdx.x / groups, grp = blockIdx.x - rank * groups;
+    if (rank >= tileCount) return;
+    const uint32_t tl = tileOrder ? tileOrder[rank] : rank;
+    const uint32_t frame0 = grp * (uint32_t)S;                                   // first frame (of the launch) of this wave's streams
+    const uint32_t nStreams = (frames - frame0 < (uint32_t)S) ? frames - frame0 : (uint32_t)S;
+    const uint32_t tile = tileFirst + tl * tileStride;
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const char* __restrict__ geom = sc.geom;
+
+    uint32_t* stk = lds + lane;                                                  // traversal stack of the stream resident in this lane: entry i at stk[i * 64]
+    uint32_t* st = lds + sc.stackDepth * 64u;                                    // parked stream state
+    float* stf = reinterpret_cast<float*>(st);
+    uint8_t* qEnd = reinterpret_cast<uint8_t*>(st + F_COUNT * S);
+    uint8_t* qBnc = qEnd + 128, * qRdy = qEnd + 256;
+
+    Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
+    uint32_t trips = 0;
+    const uint32_t items = 256u * passes;                                        // (pixel, pass) pairs in stream order
+    const uint32_t rowLen = 64u * passes;                                        // float4 per pixel row of the slab
+    const f3 camPos = mk3(sc.camPos[0], sc.camPos[1], sc.camPos[2]);
+    const f3 TL = mk3(sc.topLeft[0], sc.topLeft[1], sc.topLeft[2]);
+    const f3 TR = mk3(sc.topRight[0], sc.topRight[1], sc.topRight[2]);
+    const f3 BL = mk3(sc.bottomLeft[0], sc.bottomLeft[1], sc.bottomLeft[2]);
+
+    // every stream starts in the END queue as "fresh": the pass only generates its first primary ray
+    for (uint32_t s = lane; s < nStreams; s += 64u) {
+        st[F_SEED * S + s] = init_seed(tx + ty * (uint32_t)sc.W + (sppFirst + (frame0 + s) * passes) * 1799u);   // renderer.cpp:120
+        st[F_META * S + s] = kMetaFresh;
+        qEnd[s] = (uint8_t)s;
+    }
+    uint32_t endH = 0, endT = nStreams, bncH = 0, bncT = 0, rdyH = 0, rdyT = 0;  // queue heads / tails (wave-uniform)
+
+    // the stream resident in this lane
+    bool res = false; uint32_t sid = 0;
+    uint32_t cur = kRefDone, sp = 0;
+    f3 tO = camPos, tD = camPos, trD = camPos;                                   // ray in the space of the structure being walked
+    bool rayFinite = true;
+    Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+    rec4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;                           // pre-loaded record of `cur`
+
+#define CRT_TOP() (stk[(sp ? sp - 1u : 0u) * 64u])
+
+    // ---- the start of a stream's next scene.FindNearest, shared by both shading passes: normalise, reciprocal direction, light quad,
+    // floor plane, root step; parks the new ray and queues the stream (READY, or END / BOUNCE when the ray never enters the tree)
+    auto new_ray = [&](bool act, uint32_t s, f3 v, bool norm, f3 O, uint32_t seed, uint32_t meta) {
+        f3 D = v, rD = v; Hit nh; nh.t = 1e34f; nh.u = 0; nh.v = 0; nh.objIdx = -1; nh.triIdx = -1;
+        uint32_t ncur = kRefDone, pend = 0u;
+        if (act) {
+            const float inv = 1.0f / __builtin_sqrtf(dot3(v, v));               // normalize(): v * (1 / sqrtf(dot(v, v)))
+            D = norm ? v * inv : v;
+            rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
+            cn.rays++;
+            hit_light_floor(sc, O, D, nh);
+            if (sc.rootIsPair) {
+                // bvh.cpp:244-257 / tlas_bvh.cpp:96-110 at the root with an empty stack, from the child pair in the kernel arguments
+                const float* rp = sc.rootPair;
+                const rec4 a0 = {rp[0], rp[1], rp[2], rp[3]}, a1 = {rp[4], rp[5], rp[6], rp[7]};
+                const rec4 b0 = {rp[8], rp[9], rp[10], rp[11]}, b1 = {rp[12], rp[13], rp[14], rp[15]};
+                float d1, d2;
+                if (__builtin_amdgcn_ballot_w64(!finite3(rD)) == 0ull) { d1 = box_fast(a0, a1, O, rD, nh.t); d2 = box_fast(b0, b1, O, rD, nh.t); }
+                else { d1 = box_exact(a0, a1, O, rD, nh.t); d2 = box_exact(b0, b1, O, rD, nh.t); }
+                const bool sw = d1 > d2;
+                const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
+                const uint32_t rn = sw ? asu(b0.w) : asu(a0.w), rf = sw ? asu(a0.w) : asu(b0.w);
+                const bool hitN = dn != 1e30f;
+                pend = (hitN && df != 1e30f) ? rf : 0u;
+                ncur = hitN ? rn : kRefDone;
+                if (COUNT) { if (KIND == 0) cn.interior++; else cn.tlas++; }
+            } else ncur = sc.rootRef;
+            if (COUNT && KIND == 0 && (ncur & 0xC0000000u) == 0u && ncur != kRefDone) cn.leaf++;
+            stf[F_OX * S + s] = O.x; stf[F_OY * S + s] = O.y; stf[F_OZ * S + s] = O.z;
+            stf[F_DX * S + s] = D.x; stf[F_DY * S + s] = D.y; stf[F_DZ * S + s] = D.z;
+            stf[F_RX * S + s] = rD.x; stf[F_RY * S + s] = rD.y; stf[F_RZ * S + s] = rD.z;
+            stf[F_T * S + s] = nh.t; st[F_OBJ * S + s] = (uint32_t)nh.objIdx;
+            st[F_SEED * S + s] = seed; st[F_META * S + s] = meta;
+            st[F_CUR * S + s] = ncur; st[F_PEND * S + s] = pend;
+        }
+        // queue: the walk is needed only when the ray enters the tree; otherwise FindNearest is already over (renderer.cpp:52-55, 69)
+        const uint32_t depth = (meta >> kMetaDepthShift) & 7u;
+        const bool walk = act && ncur != kRefDone;
+        const bool toEnd = act && !walk && (nh.objIdx == -1 || nh.objIdx == 0 || (int)depth >= sc.depthLimit);
+        const bool toBnc = act && !walk && !toEnd;
+        const uint64_t mW = __builtin_amdgcn_ballot_w64(walk), mE = __builtin_amdgcn_ballot_w64(toEnd), mB = __builtin_amdgcn_ballot_w64(toBnc);
+        if (walk) qRdy[(rdyT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mW >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mW, 0u))) & kQueueMask] = (uint8_t)s;
+        if (toEnd) qEnd[(endT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mE >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mE, 0u))) & kQueueMask] = (uint8_t)s;
+        if (toBnc) qBnc[(bncT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u))) & kQueueMask] = (uint8_t)s;
+        rdyT += (uint32_t)__popcll(mW); endT += (uint32_t)__popcll(mE); bncT += (uint32_t)__popcll(mB);
+    };
+
+    for (;;) {
+        // ---------------- D. walk: state ballots of the resident streams, then the phases that have lanes ------------------------------
+        const bool isNode = res && (KIND == 1 ? (((cur >> 31) ^ (cur >> 30)) & 1u) != 0u : (cur & 0xC0000000u) == kRefInterior);
+        const bool isTri = res && cur != kRefDone && (cur & 0xC0000000u) == 0u;
+        const bool isTlas = (KIND == 1) && res && (cur & 0xC0000000u) == kRefTlasLeaf;
+        const bool runNode = __builtin_amdgcn_ballot_w64(isNode) != 0ull, runTri = __builtin_amdgcn_ballot_w64(isTri) != 0ull;
+        const bool runTlas = (KIND == 1) && __builtin_amdgcn_ballot_w64(isTlas) != 0ull;
+        // The record loads issued at the end of the previous trip are first needed here.  Naming all four tuples in one
+        // empty asm keeps the register allocator from splitting a loaded tuple across the back-edge.
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+
+        if (KIND == 1 && runTlas && isTlas) {
+            // ---------------- TLAS leaf (infra/tlas_bvh.cpp:91-95) -> enter the BLAS (BLASBVH::Intersect, blas_bvh.cpp:376-381) ----------
+            if (COUNT) { cn.tlas++; cn.visits++; }
+            const f3 O = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
+            const f3 D = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
+            to_object_space(q0, q1, q2, O, D, tO, tD, trD);
+            rayFinite = finite3(trD);
+            stk[sp * 64u] = kRefReturn; sp++;
+            const uint32_t next = asu(q3.z);                                       // Instance::rootRef
+            if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+            cur = next;
+        }
+        if (runNode) {
+            // ---------------- NODE phase (infra/bvh.cpp:244-257) ------------------------------------------------------------------------
+            const bool allFinite = __builtin_amdgcn_ballot_w64(isNode && !rayFinite) == 0ull;
+            if (isNode) {
+                if (COUNT) { if (KIND == 1 && (cur & kRefTlasBit) != 0u) cn.tlas++; else cn.interior++; }
+                uint32_t top = CRT_TOP();                                          // speculative: lands during the slab arithmetic
+                float d1, d2;
+                if (allFinite) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
+                else { d1 = box_exact(q0, q1, tO, trD, h.t); d2 = box_exact(q2, q3, tO, trD, h.t); }
+                const bool sw = d1 > d2;                                           // near child first (strict >: ties keep child 1)
+                const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
+                const uint32_t rn = sw ? asu(q2.w) : asu(q0.w), rf = sw ? asu(q0.w) : asu(q2.w);
+                stk[sp * 64u] = rf;                                                // dead store unless `push`
+                const bool hitN = dn != 1e30f, push = hitN && df != 1e30f;
+                bool pop = !hitN && sp != 0u;
+                uint32_t next = hitN ? rn : (pop ? top : kRefDone);
+                sp = sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
+                if (KIND == 1 && next == kRefReturn) {                             // BLAS finished: back to the world-space ray, pop the TLAS entry below
+                    tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
+                    tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
+                    trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
+                    rayFinite = finite3(trD);
+                    pop = sp != 0u; top = CRT_TOP();
+                    next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
+                }
+                if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+                cur = next;
+            }
+        }
+        if (runTri && isTri) {
+            // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:203-222, 232-243) -------------------------------
+            if (COUNT) cn.tri++;
+            uint32_t top = CRT_TOP();
+            hit_tri(q0, q1, q2, tO, tD, h);
+            const bool more = asu(q2.w) > 1u;                                      // next LeafTri of this leaf (48 B = 3 units)
+            bool pop = !more && sp != 0u;
+            uint32_t next = more ? cur + 3u : (pop ? top : kRefDone);
+            sp -= pop ? 1u : 0u;
+            if (KIND == 1 && next == kRefReturn) {
+                tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
+                tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
+                trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
+                rayFinite = finite3(trD);
+                pop = sp != 0u; top = CRT_TOP();
+                next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
+            }
+            if (COUNT && !more && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+            cur = next;
+        }
+        asm volatile("" ::: "memory");
+        // ---------------- A. swap out: streams whose walk is over park their hit and queue for shading ------------------------------
+        {
+            const bool fin = res && cur == kRefDone;
+            if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
+                bool toEnd = false;
+                if (fin) {
+                    stf[F_T * S + sid] = h.t; stf[F_U * S + sid] = h.u; stf[F_V * S + sid] = h.v;
+                    st[F_OBJ * S + sid] = (uint32_t)h.objIdx; st[F_TRI * S + sid] = (uint32_t)h.triIdx;
+                    const uint32_t depth = (st[F_META * S + sid] >> kMetaDepthShift) & 7u;
+                    toEnd = h.objIdx == -1 || h.objIdx == 0 || (int)depth >= sc.depthLimit;
+                    res = false;
+                }
+                const uint64_t mE = __builtin_amdgcn_ballot_w64(fin && toEnd), mB = __builtin_amdgcn_ballot_w64(fin && !toEnd);
+                if (fin && toEnd) qEnd[(endT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mE >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mE, 0u))) & kQueueMask] = (uint8_t)sid;
+                if (fin && !toEnd) qBnc[(bncT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u))) & kQueueMask] = (uint8_t)sid;
+                endT += (uint32_t)__popcll(mE); bncT += (uint32_t)__popcll(mB);
+            }
+        }
+        asm volatile("" ::: "memory");          // (the sections exchange stream state through LDS across lanes: nothing is carried over in registers)
+        const uint64_t mRes = __builtin_amdgcn_ballot_w64(res);
+        const uint32_t nRes = (uint32_t)__popcll(mRes);
+        {
+            const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH;
+            if (nEnd + nBnc + nRdy + nRes == 0u) break;
+            if (COUNT) trips++;
+        }
+        asm volatile("" ::: "memory");
+        // ---------------- C. swap in: free lanes take the next READY streams -----------------------------------------------------------
+        {
+            const uint32_t nRdy = rdyT - rdyH;
+            const uint64_t mFree = ~__builtin_amdgcn_ballot_w64(res);
+            if (nRdy != 0u && mFree != 0ull) {
+                const uint32_t myRank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mFree >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mFree, 0u));
+                if (!res && myRank < nRdy) {
+                    sid = qRdy[(rdyH + myRank) & kQueueMask];
+                    tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
+                    tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
+                    trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
+                    h.t = stf[F_T * S + sid]; h.objIdx = (int)st[F_OBJ * S + sid]; h.u = 0; h.v = 0; h.triIdx = -1;
+                    cur = st[F_CUR * S + sid];
+                    const uint32_t pend = st[F_PEND * S + sid];
+                    stk[0] = pend; sp = pend ? 1u : 0u;                            // a dead store unless the far root child was hit
+                    rayFinite = finite3(trD);
+                    res = true;
+                }
+                const uint32_t nFree = (uint32_t)__popcll(mFree);
+                rdyH += nRdy < nFree ? nRdy : nFree;
+            }
+        }
+        // ---------------- E. issue the record loads of the resident streams (consumed by the next trip) ----------------------------------
+        {
+            const bool want = res && cur != kRefDone;
+            uint32_t oa = (cur & kRefOffsetMask) << 4;                             // NodePair / LeafTri
+            uint32_t ob = oa + 32u;
+            if (KIND == 1 && (cur & kRefTlasBit) != 0u) {
+                if (cur & kRefInterior) { oa = sc.instOff + (cur & 0xffffu) * 128u; ob = oa + 32u; }                // TLAS leaf: Instance {invT rows, ids}
+                else { oa = sc.tlasOff + (cur & 0x7fffu) * 32u; ob = sc.tlasOff + ((cur >> 15) & 0x7fffu) * 32u; } // TLAS interior: the two child nodes
+            }
+            if (!want) { oa = 0u; ob = 32u; }
+            if (__builtin_amdgcn_ballot_w64(want) != 0ull) { q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, ob); q3 = ldg(geom, ob + 16u); }
+        }
+        asm volatile("" ::: "memory");
+        {
+            // ---------------- B. shading passes (their latency-free arithmetic also covers the record loads just issued) --------------------
+            const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH, nRes = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(res));
+            // a shading pass waits for a full wavefront of streams unless the walking side runs dry
+            const bool starving = nRes + nRdy < (uint32_t)CRT_POOL_STARVE;
+            const bool runEnd = nEnd >= (uint32_t)CRT_POOL_SHADE_MIN || (starving && nEnd > 0u && nEnd >= nBnc);
+            const bool runBnc = nBnc >= (uint32_t)CRT_POOL_SHADE_MIN || (starving && nBnc > nEnd);
+
+            if (runEnd) {
+                // ---------------- B1. END pass: the path of each stream ended (renderer.cpp:54-55, 69) or has not begun ----------------
+                const uint32_t n = nEnd < 64u ? nEnd : 64u;
+                const bool act = lane < n;
+                const uint32_t s = act ? qEnd[(endH + lane) & kQueueMask] : 0u;
+                endH += n;
+                uint32_t meta = 0, seed = 0; int obj = -1; f3 D = camPos;
+                if (act) { meta = st[F_META * S + s]; seed = st[F_SEED * S + s]; obj = (int)st[F_OBJ * S + s]; D = mk3(stf[F_DX * S + s], stf[F_DY * S + s], stf[F_DZ * S + s]); }
+                const bool first = (meta & kMetaFresh) != 0u;
+                const int depth = (int)((meta >> kMetaDepthShift) & 7u);
+                uint32_t item = meta & kMetaItemMask;
+                const bool ended = act && !first, miss = ended && obj == -1;
+                if (ended && obj >= 2) cn.meshhits++;
+                f3 L = mk3(0, 0, 0);
+                if (miss) {                                                       // GetSkyColor, file_scene.cpp:142-154
+                    const float phi = crt_atan2f(-D.z, D.x) + CRT_PI, theta = crt_acosf(-D.y);
+                    L = tex_sample(sc, sc.skyOffset, sc.skyW, sc.skyH, phi * CRT_INV2PI, theta * CRT_INVPI);
+                } else if (ended) L = (depth >= sc.depthLimit) ? mk3(0, 0, 0) : mk3(24, 24, 22);   // depth limit -> 0; GetLightColor, file_scene.cpp:164-167
+                bool gen = act && first;
+                if (ended) {
+                    // unwind the recursion (innermost factor first: albedo*medium*Sample(...) multiplies on return), store the sample
+#pragma unroll
+                    for (int k = 4; k >= 0; k--)
+                        if (depth > k) L = mk3(stf[(F_FAC + 3 * k) * S + s], stf[(F_FAC + 3 * k + 1) * S + s], stf[(F_FAC + 3 * k + 2) * S + s]) * L;
+                    uint32_t pix = item, pass = 0;
+                    if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
+                    const uint32_t fr = frame0 + s;                                // frame of the launch -> (64-frame window, sample row position)
+                    slab[(((size_t)(fr >> 6) * tileCount + tl) * 256u + pix) * rowLen + ((fr & 63u) * passes + pass)] = make_float4(L.x, L.y, L.z, 0.0f);
+                    item++;
+                    gen = item < items;                                            // else: the stream has rendered its 256 pixels
+                }
+                f3 v = camPos;
+                if (gen) {                                                         // ProcessTile + Camera::GetPrimaryRay (renderer.cpp:125-126, camera.h:23-30)
+                    const uint32_t pix = (passes == 1u) ? item : item / passes;
+                    const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
+                    const float jy = rnd(seed);                                    // pinned: first draw is the y jitter
+                    const float jx = rnd(seed);
+                    const float u = ((float)x + jx) * sc.invW, vv = ((float)y + jy) * sc.invH;
+                    const f3 P = TL + u * (TR - TL) + vv * (BL - TL);
+                    v = P - camPos;
+                    cn.primary++;
+                }
+                new_ray(gen, s, v, true, camPos, seed, item);                      // depth 0, outside, not fresh
+            }
+            asm volatile("" ::: "memory");
+            if (runBnc) {
+                // ---------------- B2. BOUNCE pass: surface hit (floor or mesh) below the depth limit (renderer.cpp:56-99) ----------------
+                const uint32_t n = nBnc < 64u ? nBnc : 64u;
+                const bool act = lane < n;
+                const uint32_t s = act ? qBnc[(bncH + lane) & kQueueMask] : 0u;
+                bncH += n;
+                f3 O = camPos, D = camPos; float ht = 0, hu = 0, hv = 0; int obj = 1; uint32_t tri = 0, seed = 0, meta = 0;
+                if (act) {
+                    obj = (int)st[F_OBJ * S + s]; tri = st[F_TRI * S + s];
+                    O = mk3(stf[F_OX * S + s], stf[F_OY * S + s], stf[F_OZ * S + s]);
+                    D = mk3(stf[F_DX * S + s], stf[F_DY * S + s], stf[F_DZ * S + s]);
+                    ht = stf[F_T * S + s]; hu = stf[F_U * S + s]; hv = stf[F_V * S + s];
+                    seed = st[F_SEED * S + s]; meta = st[F_META * S + s];
+                }
+                const bool mesh = act && obj >= 2;
+                rec4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;                 // the hit triangle's ShadeTri
+                if (mesh) { const uint32_t so = sc.shadeOff + tri * 64u; s0 = ldg(geom, so); s1 = ldg(geom, so + 16u); s2 = ldg(geom, so + 32u); s3 = ldg(geom, so + 48u); cn.meshhits++; }
+                const bool inside = (meta & kMetaInside) != 0u;
+                const int depth = (int)((meta >> kMetaDepthShift) & 7u);
+                const uint32_t item = meta & kMetaItemMask;
+                float tu = 0, tv = 0; uint32_t tOff = 0; int tW = 0, tH = 0;
+                f3 I = O, N = O, absorb = O; float refl = 0, refr = 0;
+                f3 v = O, pre = O; bool norm = false, diffuse = false, newInside = false;
+                if (act) {
+                    I = O + ht * D;
+                    if (obj == 1) {                                                // floor: Plane::GetNormal / GetUV (primitives.h:112-133)
+                        N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
+                        if (N.y == 1) {
+                            float u = I.x, vv = I.z;
+                            u *= sc.floorInvto; vv *= sc.floorInvto;
+                            tu = u - __builtin_floorf(u); tv = vv - __builtin_floorf(vv);
+                        }
+                        refl = sc.floorMat.reflectivity; refr = sc.floorMat.refractivity;
+                        absorb = mk3(sc.floorMat.absorption[0], sc.floorMat.absorption[1], sc.floorMat.absorption[2]);
+                        tOff = sc.floorMat.texOffset; tW = sc.floorMat.texW; tH = sc.floorMat.texH;
+                    } else {                                                       // mesh: GetNormal / GetUV (bvh.cpp:290-305, blas_bvh.cpp:391-406)
+                        const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+                        const float w = 1 - hu - hv;
+                        const f3 Nn = w * n0 + hu * n1 + hv * n2;
+                        tu = w * s2.y + hu * s2.w + hv * s3.y;
+                        tv = w * s2.z + hu * s3.x + hv * s3.z;
+                        const rec4* mp = reinterpret_cast<const rec4*>(sc.mats + (int)asu(s3.w));
+                        const rec4 m0 = mp[0], m1 = mp[1];
+                        refl = m0.x; refr = m0.y; absorb = mk3(m0.z, m0.w, m1.x);
+                        tOff = asu(m1.y); tW = (int)asu(m1.z); tH = (int)asu(m1.w);
+                        if (KIND == 0) {
+                            N = normalize3(Nn);
+                        } else {
+                            const uint32_t io = sc.instOff + (uint32_t)(obj - 2) * 128u + 64u;   // Instance::T rows
+                            const rec4 r0 = ldg(geom, io), r1 = ldg(geom, io + 16), r2 = ldg(geom, io + 32);
+                            N = normalize3(mk3(r0.x * Nn.x + r0.y * Nn.y + r0.z * Nn.z + r0.w * 0.0f,
+                                               r1.x * Nn.x + r1.y * Nn.y + r1.z * Nn.z + r1.w * 0.0f,
+                                               r2.x * Nn.x + r2.y * Nn.y + r2.z * Nn.z + r2.w * 0.0f));
+                        }
+                    }
+                    if (dot3(N, D) > 0) N = -N;
+                    f3 c = mk3(1.0f, 1.0f, 1.0f);
+                    if (tW > 0) c = tex_sample(sc, tOff, tW, tH, tu, tv);          // Material::GetAlbedo
+                    f3 medium = mk3(1, 1, 1);
+                    if (inside) {
+                        const f3 ab = absorb * -ht;
+                        medium = mk3(crt_expf(ab.x), crt_expf(ab.y), crt_expf(ab.z));
+                    }
+                    const float r = rnd(seed);
+                    if (r < refl) {                                                // HandleMirror, renderer.cpp:20-25
+                        v = D - 2.0f * N * dot3(N, D);
+                        pre = c * medium;
+                    } else if (r < refl + refr) {                                  // HandleDielectric, renderer.cpp:27-45
+                        v = D - 2.0f * N * dot3(N, D);
+                        const float n1 = inside ? 1.2f : 1, n2 = inside ? 1 : 1.2f;
+                        const float eta = n1 / n2, cosi = dot3(-D, N);
+                        const float cost2 = 1.0f - eta * eta * (1 - cosi * cosi);
+                        if (cost2 > 0) {
+                            const float a = n1 - n2, b2 = n1 + n2, R0 = (a * a) / (b2 * b2), cc = 1 - cosi;
+                            const float Fr = R0 + (1 - R0) * (cc * cc * cc * cc * cc);
+                            const f3 T = eta * D + ((eta * cosi - __builtin_sqrtf(__builtin_fabsf(cost2))) * N);
+                            if (rnd(seed) > Fr) { v = T; newInside = !inside; }
+                        }
+                        pre = c * medium;
+                    } else {                                                       // diffuse, renderer.cpp:93-99; diffusereflection tmplmath.h:535-544
+                        f3 Rr;
+                        do {
+                            const float rz = rnd_pm1(seed);                        // draw order pinned z, y, x
+                            const float ry = rnd_pm1(seed);
+                            const float rx = rnd_pm1(seed);
+                            Rr = mk3(rx, ry, rz);
+                        } while (dot3(Rr, Rr) > 1);
+                        if (dot3(Rr, N) < 0) Rr = Rr * -1.0f;
+                        v = Rr; norm = true; diffuse = true;
+                        const f3 brdf = c * CRT_INVPI;
+                        pre = medium * brdf * 2.0f * CRT_PI;                       // ... * dot(R, N) once R is normalised
+                    }
+                    // normalize(R) of the diffuse branch; the bounce's throughput factor and the new origin use the normalised direction
+                    const float inv = 1.0f / __builtin_sqrtf(dot3(v, v));
+                    const f3 nv = norm ? v * inv : v;
+                    v = nv;
+                    const f3 factor = diffuse ? pre * dot3(nv, N) : pre;
+                    stf[(F_FAC + 3 * depth) * S + s] = factor.x; stf[(F_FAC + 3 * depth + 1) * S + s] = factor.y; stf[(F_FAC + 3 * depth + 2) * S + s] = factor.z;   // depth <= 4 here
+                    O = I + nv * CRT_EPS;
+                }
+                new_ray(act, s, v, false, O, seed, item | ((uint32_t)(depth + 1) << kMetaDepthShift) | (newInside ? kMetaInside : 0u));
+            }
+        }
+    }
+#undef CRT_TOP
+
+    if (COUNT && tileClocks && lane == 0 && groups == 1u) {                     // instrumentation: per-tile wall time + loop trips (one group per tile only)
+        tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
+        tileClocks[2 * tl + 1] = trips;
+    }
+    uint32_t vals[8] = {cn.rays, cn.primary, cn.interior, cn.leaf, cn.tri, cn.tlas, cn.visits, cn.meshhits};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (!COUNT && i >= 2 && i != 7) continue;
+        uint32_t sum = wave_sum(vals[i]);
+        if (lane == 0 && sum) atomicAdd(&counters->v[i], (unsigned long long)sum);
+    }
+}
+
+} // namespace crt
+
+// streams per wavefront: 128 for jobs of >= 128 frames, 64 (streams = lanes) for shorter ones
+extern "C" uint32_t crt_pool_streams(uint32_t frames) { return frames > 64u ? 128u : 64u; }
+extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackBytes, uint32_t streams) { return stackBytes + crt::F_COUNT * streams * 4u + 3u * 128u; }
+
+extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
+                                             uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
+                                             uint32_t frames, uint32_t passes, uint32_t stackBytes, int collectStats, hipStream_t stream)
+{
+    if (tileCount == 0 || frames == 0) return hipSuccess;
+    const uint32_t S = crt_pool_streams(frames);
+    const uint32_t groups = (frames + S - 1u) / S;
+    if ((unsigned long long)tileCount * groups > 0x7fffffffull) return hipErrorInvalidValue;
+    dim3 grid(tileCount * groups), block(64);
+    const uint32_t ldsBytes = crt_pool_lds_bytes(stackBytes, S);
+#define CRT_LAUNCH(K, C, SS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups)
+#define CRT_LAUNCH_S(K, C) do { if (S == 128u) CRT_LAUNCH(K, C, 128); else CRT_LAUNCH(K, C, 64); } while (0)
+    if (sc->kind == 0) { if (collectStats) CRT_LAUNCH_S(0, true); else CRT_LAUNCH_S(0, false); }
+    else { if (collectStats) CRT_LAUNCH_S(1, true); else CRT_LAUNCH_S(1, false); }
+#undef CRT_LAUNCH_S
+#undef CRT_LAUNCH
+    return hipGetLastError();
+}
