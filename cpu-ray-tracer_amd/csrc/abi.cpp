@@ -17,7 +17,8 @@
 #include <vector>
 
 extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
-extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
+extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_whitted(const crt::Scene*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
@@ -425,7 +426,10 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     s.tlasOff = (uint32_t)tlasOffB; s.instOff = (uint32_t)instOffB; s.shadeOff = (uint32_t)shadeOffB;
     if ((r = upload(c, mats, &s.mats))) return r;
     s.rootRef = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot : rootRef0;
-    s.bvhStack = maxHeight + 2;
+    // Traversal stack entries (LDS is what limits the waves per SIMD, so no slack): the ordered traversal keeps at most one pending sibling per level
+    // below the root, i.e. <= height entries, and its dead store (the far child is written to slot sp before the push is decided) happens at an
+    // interior node, where sp <= height - 1.  Two-level scenes add the TLAS entries and the return marker below the BLAS part.
+    s.bvhStack = maxHeight > 0 ? maxHeight : 1;
     // the root's two children also travel in the kernel arguments: the render kernel takes every ray's first traversal step from scalar registers
     s.rootIsPair = 0; memset(s.rootPair, 0, sizeof(s.rootPair));
     if (sd->kind == CRT_SCENE_TLAS) {
@@ -438,7 +442,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         s.rootIsPair = 1;
     }
     if (getenv("CRT_DEBUG_NO_ROOTPAIR")) s.rootIsPair = 0;                            // tests: every ray starts at the root reference instead
-    s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 3 : 0);   // + TLAS pushes + the return marker + slack
+    s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 1 : 0);   // + TLAS pushes + the return marker
     c->ldsBytes = s.stackDepth * 64u * 4u;
     if (const char* e = getenv("CRT_DEBUG_EXTRA_LDS")) c->ldsBytes += (uint32_t)atoi(e);   // occupancy experiments only
     if (c->ldsBytes + 15u * 256u > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "tree height %u (+TLAS %u) needs %u bytes of LDS traversal stack per wave (> 64 KiB)", maxHeight, tlasHeight, c->ldsBytes);
@@ -507,6 +511,11 @@ static int update_tile_order(crt_ctx* c)
     return 0;
 }
 
+// bytes one 64-frame window of a launch takes in the slab pool: its float4 samples + (stream-pool kernel) the throughput-factor scratch.
+// A launch's region = [samples of all its windows][scratch of all its windows].
+static size_t sample_bytes_per_window(const crt_ctx* c, uint32_t passes) { return (size_t)c->tileCount * 256u * 64u * passes * 16u; }
+static size_t window_bytes(const crt_ctx* c, uint32_t passes) { return sample_bytes_per_window(c, passes) + (c->usePool ? crt_pool_scratch_bytes_per_window(c->tileCount) : 0); }
+
 static int take_event(crt_ctx* c, std::vector<EventPair>& list, EventPair* out)
 {
     EventPair ev;
@@ -524,7 +533,7 @@ static int take_event(crt_ctx* c, std::vector<EventPair>& list, EventPair* out)
 // overlap on the streams), never more than half of the free HBM.
 static int ensure_pool(crt_ctx* c, uint32_t frames, uint32_t passes, uint32_t* maxFOut)
 {
-    const size_t windowBytes = (size_t)c->tileCount * 256u * 64u * passes * 16u;
+    const size_t windowBytes = window_bytes(c, passes);
     uint32_t maxF = (uint32_t)c->cfg.maxFramesPerLaunch;
     uint32_t maxW = maxF >= 64u ? maxF / 64u : 1u;
     const uint32_t wantW = (frames + 63u) / 64u;                                          // (an upper bound when maxF < 64)
@@ -611,7 +620,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     }
     uint32_t maxF = 0;
     { int r = ensure_pool(c, frames, passes, &maxF); if (r) return r; }
-    const size_t windowBytes = (size_t)c->tileCount * 256u * 64u * passes * 16u;
+    const size_t windowBytes = window_bytes(c, passes);
     for (uint32_t f0 = 0; f0 < frames; f0 += maxF) {
         const uint32_t nf = (frames - f0 < maxF) ? frames - f0 : maxF;
         hipStream_t st = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
@@ -621,8 +630,12 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         EventPair ev;
         if ((r = take_event(c, c->evRender, &ev))) return r;
         HIPCK(c, hipEventRecord(ev.a, st));
-        HIPCK(c, (c->usePool ? crt_launch_render_pool : crt_launch_render)(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, st));
+        if (c->usePool)
+            HIPCK(c, crt_launch_render_pool(&c->hScene, slab, (char*)slab + (size_t)((nf + 63u) / 64u) * sample_bytes_per_window(c, passes), c->dCounters, c->dTileClocks, c->dTileOrder,
+                                            c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, st));
+        else
+            HIPCK(c, crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, st));
         HIPCK(c, hipEventRecord(ev.b, st));
         // ordered accumulation on the main stream (frame order = launch order), behind this launch
         HIPCK(c, hipStreamWaitEvent(c->stream, ev.b, 0));

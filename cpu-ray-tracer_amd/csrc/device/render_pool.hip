@@ -7,7 +7,7 @@
 //   * a stream that is WALKING the acceleration structure is resident in a lane: its ray, nearest hit, node reference and
 //     pre-loaded node / triangle record live in that lane's registers, its traversal stack in the lane's LDS column;
 //   * a stream that WAITS for shading is parked in LDS (ray, hit, RNG state, pixel counter, the path's throughput factors —
-//     33 dwords) and queued by what it needs next: the END queue (the path ended: sky lookup or light / depth limit, unwind the
+//     14 dwords; the path's throughput factors in a global scratch area) and queued by what it needs next: the END queue (the path ended: sky lookup or light / depth limit, unwind the
 //     throughput factors, store the sample, generate the next pixel's primary ray) or the BOUNCE queue (surface hit: normal,
 //     uv, albedo, mirror / dielectric / rejection-sampled diffuse direction);
 //   * a shading pass takes up to 64 streams from ONE queue — all lanes run the same branch of Renderer::Sample — starts each
@@ -26,14 +26,20 @@ namespace crt {
 
 // parked stream state, SoA in LDS: field f of stream s at st[f * S + s]
 enum : uint32_t {
-    F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_RX, F_RY, F_RZ,   // ray origin, direction, reciprocal direction (world space)
-    F_T, F_U, F_V, F_OBJ, F_TRI,                                 // nearest hit: FindNearest's result once the walk is over
-    F_SEED, F_META,                                              // RNG state; item | depth << 11 | inside << 14 | fresh << 15
-    F_CUR, F_PEND,                                               // READY streams: node reference to start at, far root child to push (0 = none)
-    F_FAC,                                                       // 15 throughput factors: component j of depth k at F_FAC + 3k + j
-    F_COUNT = F_FAC + 15
+    F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ,                      // ray origin, direction (world space)
+    F_RX, F_RY, F_RZ,                                            // reciprocal direction: needed until the walk is over (swap-in, return from a BLAS)
+    F_T,                                                         // nearest hit distance: after the quad / plane tests, then FindNearest's result
+    F_SEED, F_META,                                              // RNG state; item | depth << 11 | inside << 14 | fresh << 15 | (hit objIdx + 1) << 16
+    F_U, F_V,                                                    // barycentrics of a mesh hit (after the walk)
+    F_COUNT,                                                     // 14 dwords = 56 bytes per parked stream
+    // slots with two lives:
+    F_CUR = F_U, F_PEND = F_V,                                   // what a READY stream needs before the walk: node reference to start at, far root child to push (0 = none)
+    F_TRI = F_RX                                                 // after the walk: the hit triangle's global shade index
 };
-constexpr uint32_t kMetaItemMask = 0x7ffu, kMetaDepthShift = 11u, kMetaInside = 1u << 14, kMetaFresh = 1u << 15;
+// The path's throughput factors (albedo*medium*... of each bounce, multiplied on unwind: 15 floats, written once per bounce, read once
+// per path) live in a global scratch area behind the launch's sample slab instead of LDS — 8 KB per wave that buy a third wave per SIMD:
+// component j of depth k of stream s of block b at fac[(b * 15 + 3k + j) * S + s].
+constexpr uint32_t kMetaItemMask = 0x7ffu, kMetaDepthShift = 11u, kMetaInside = 1u << 14, kMetaFresh = 1u << 15, kMetaObjShift = 16u, kMetaLowMask = 0xffffu;
 constexpr uint32_t kQueueMask = 127u;                            // queues are rings of 128 one-byte stream ids (S <= 128)
 
 #ifndef CRT_POOL_SHADE_MIN
@@ -44,7 +50,7 @@ constexpr uint32_t kQueueMask = 127u;                            // queues are r
 #endif
 
 template <int KIND, bool COUNT, int S>
-__global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, Counters* __restrict__ counters,
+__global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
                                                              unsigned long long* __restrict__ tileClocks, const uint32_t* __restrict__ tileOrder,
                                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                              uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t groups)
@@ -61,6 +67,7 @@ __global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, floa
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const char* __restrict__ geom = sc.geom;
+    float* __restrict__ fac = facScratch + (size_t)blockIdx.x * (15u * (uint32_t)S);
 
     uint32_t* stk = lds + lane;                                                  // traversal stack of the stream resident in this lane: entry i at stk[i * 64]
     uint32_t* st = lds + sc.stackDepth * 64u;                                    // parked stream state
@@ -126,8 +133,8 @@ __global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, floa
             stf[F_OX * S + s] = O.x; stf[F_OY * S + s] = O.y; stf[F_OZ * S + s] = O.z;
             stf[F_DX * S + s] = D.x; stf[F_DY * S + s] = D.y; stf[F_DZ * S + s] = D.z;
             stf[F_RX * S + s] = rD.x; stf[F_RY * S + s] = rD.y; stf[F_RZ * S + s] = rD.z;
-            stf[F_T * S + s] = nh.t; st[F_OBJ * S + s] = (uint32_t)nh.objIdx;
-            st[F_SEED * S + s] = seed; st[F_META * S + s] = meta;
+            stf[F_T * S + s] = nh.t;
+            st[F_SEED * S + s] = seed; st[F_META * S + s] = meta | ((uint32_t)(nh.objIdx + 1) << kMetaObjShift);
             st[F_CUR * S + s] = ncur; st[F_PEND * S + s] = pend;
         }
         // queue: the walk is needed only when the ray enters the tree; otherwise FindNearest is already over (renderer.cpp:52-55, 69)
@@ -222,8 +229,10 @@ __global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, floa
                 bool toEnd = false;
                 if (fin) {
                     stf[F_T * S + sid] = h.t; stf[F_U * S + sid] = h.u; stf[F_V * S + sid] = h.v;
-                    st[F_OBJ * S + sid] = (uint32_t)h.objIdx; st[F_TRI * S + sid] = (uint32_t)h.triIdx;
-                    const uint32_t depth = (st[F_META * S + sid] >> kMetaDepthShift) & 7u;
+                    st[F_TRI * S + sid] = (uint32_t)h.triIdx;
+                    const uint32_t meta = st[F_META * S + sid];
+                    st[F_META * S + sid] = (meta & kMetaLowMask) | ((uint32_t)(h.objIdx + 1) << kMetaObjShift);
+                    const uint32_t depth = (meta >> kMetaDepthShift) & 7u;
                     toEnd = h.objIdx == -1 || h.objIdx == 0 || (int)depth >= sc.depthLimit;
                     res = false;
                 }
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, floa
                     tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
                     tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
                     trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
-                    h.t = stf[F_T * S + sid]; h.objIdx = (int)st[F_OBJ * S + sid]; h.u = 0; h.v = 0; h.triIdx = -1;
+                    h.t = stf[F_T * S + sid]; h.objIdx = (int)(st[F_META * S + sid] >> kMetaObjShift) - 1; h.u = 0; h.v = 0; h.triIdx = -1;
                     cur = st[F_CUR * S + sid];
                     const uint32_t pend = st[F_PEND * S + sid];
                     stk[0] = pend; sp = pend ? 1u : 0u;                            // a dead store unless the far root child was hit
@@ -292,12 +301,23 @@ __global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, floa
                 const uint32_t s = act ? qEnd[(endH + lane) & kQueueMask] : 0u;
                 endH += n;
                 uint32_t meta = 0, seed = 0; int obj = -1; f3 D = camPos;
-                if (act) { meta = st[F_META * S + s]; seed = st[F_SEED * S + s]; obj = (int)st[F_OBJ * S + s]; D = mk3(stf[F_DX * S + s], stf[F_DY * S + s], stf[F_DZ * S + s]); }
+                if (act) { meta = st[F_META * S + s]; seed = st[F_SEED * S + s]; obj = (int)(meta >> kMetaObjShift) - 1; D = mk3(stf[F_DX * S + s], stf[F_DY * S + s], stf[F_DZ * S + s]); }
                 const bool first = (meta & kMetaFresh) != 0u;
                 const int depth = (int)((meta >> kMetaDepthShift) & 7u);
                 uint32_t item = meta & kMetaItemMask;
                 const bool ended = act && !first, miss = ended && obj == -1;
                 if (ended && obj >= 2) cn.meshhits++;
+                // the path's throughput factors: fetched now (device-scope loads: they were written by this wave's BOUNCE passes, possibly from
+                // another lane), needed after the sky lookup; most paths end at depth 0..2 and a level is fetched only by the lanes that deep
+                float fk[15];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    fk[3 * k] = fk[3 * k + 1] = fk[3 * k + 2] = 0.0f;
+                    if (ended && depth > k) {
+#pragma unroll
+                        for (int j = 0; j < 3; j++) fk[3 * k + j] = __hip_atomic_load(fac + (3 * k + j) * S + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 f3 L = mk3(0, 0, 0);
                 if (miss) {                                                       // GetSkyColor, file_scene.cpp:142-154
                     const float phi = crt_atan2f(-D.z, D.x) + CRT_PI, theta = crt_acosf(-D.y);
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, floa
                     // unwind the recursion (innermost factor first: albedo*medium*Sample(...) multiplies on return), store the sample
 #pragma unroll
                     for (int k = 4; k >= 0; k--)
-                        if (depth > k) L = mk3(stf[(F_FAC + 3 * k) * S + s], stf[(F_FAC + 3 * k + 1) * S + s], stf[(F_FAC + 3 * k + 2) * S + s]) * L;
+                        if (depth > k) L = mk3(fk[3 * k], fk[3 * k + 1], fk[3 * k + 2]) * L;
                     uint32_t pix = item, pass = 0;
                     if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
                     const uint32_t fr = frame0 + s;                                // frame of the launch -> (64-frame window, sample row position)
@@ -338,11 +358,11 @@ __global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, floa
                 bncH += n;
                 f3 O = camPos, D = camPos; float ht = 0, hu = 0, hv = 0; int obj = 1; uint32_t tri = 0, seed = 0, meta = 0;
                 if (act) {
-                    obj = (int)st[F_OBJ * S + s]; tri = st[F_TRI * S + s];
+                    tri = st[F_TRI * S + s];
                     O = mk3(stf[F_OX * S + s], stf[F_OY * S + s], stf[F_OZ * S + s]);
                     D = mk3(stf[F_DX * S + s], stf[F_DY * S + s], stf[F_DZ * S + s]);
                     ht = stf[F_T * S + s]; hu = stf[F_U * S + s]; hv = stf[F_V * S + s];
-                    seed = st[F_SEED * S + s]; meta = st[F_META * S + s];
+                    seed = st[F_SEED * S + s]; meta = st[F_META * S + s]; obj = (int)(meta >> kMetaObjShift) - 1;
                 }
                 const bool mesh = act && obj >= 2;
                 rec4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;                 // the hit triangle's ShadeTri
@@ -427,7 +447,10 @@ __global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, floa
                     const f3 nv = norm ? v * inv : v;
                     v = nv;
                     const f3 factor = diffuse ? pre * dot3(nv, N) : pre;
-                    stf[(F_FAC + 3 * depth) * S + s] = factor.x; stf[(F_FAC + 3 * depth + 1) * S + s] = factor.y; stf[(F_FAC + 3 * depth + 2) * S + s] = factor.z;   // depth <= 4 here
+                    float* fd = fac + (3 * depth) * S + s;                         // depth <= 4 here
+                    __hip_atomic_store(fd, factor.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(fd + S, factor.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(fd + 2 * S, factor.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     O = I + nv * CRT_EPS;
                 }
                 new_ray(act, s, v, false, O, seed, item | ((uint32_t)(depth + 1) << kMetaDepthShift) | (newInside ? kMetaInside : 0u));
@@ -452,10 +475,16 @@ __global__ __launch_bounds__(64, 2) void render_pool_kernel(const Scene sc, floa
 } // namespace crt
 
 // streams per wavefront: 128 for jobs of >= 128 frames, 64 (streams = lanes) for shorter ones
-extern "C" uint32_t crt_pool_streams(uint32_t frames) { return frames > 64u ? 128u : 64u; }
+#ifndef CRT_POOL_STREAMS
+#define CRT_POOL_STREAMS 128
+#endif
+extern "C" uint32_t crt_pool_streams(uint32_t frames) { return frames > 64u ? (uint32_t)CRT_POOL_STREAMS : 64u; }
 extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackBytes, uint32_t streams) { return stackBytes + crt::F_COUNT * streams * 4u + 3u * 128u; }
+// bytes of throughput-factor scratch a launch of `windows` 64-frame windows needs behind its sample slab (15 floats per stream; a wave's
+// group of streams may reach past the last window, hence 128 stream slots per window)
+extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t tileCount) { return (size_t)tileCount * 128u * 15u * 4u; }
 
-extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
+extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, void* facScratch, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
                                              uint32_t frames, uint32_t passes, uint32_t stackBytes, int collectStats, hipStream_t stream)
 {
@@ -465,8 +494,8 @@ extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, c
     if ((unsigned long long)tileCount * groups > 0x7fffffffull) return hipErrorInvalidValue;
     dim3 grid(tileCount * groups), block(64);
     const uint32_t ldsBytes = crt_pool_lds_bytes(stackBytes, S);
-#define CRT_LAUNCH(K, C, SS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups)
-#define CRT_LAUNCH_S(K, C) do { if (S == 128u) CRT_LAUNCH(K, C, 128); else CRT_LAUNCH(K, C, 64); } while (0)
+#define CRT_LAUNCH(K, C, SS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups)
+#define CRT_LAUNCH_S(K, C) do { if (S == 64u) CRT_LAUNCH(K, C, 64); else CRT_LAUNCH(K, C, CRT_POOL_STREAMS); } while (0)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH_S(0, true); else CRT_LAUNCH_S(0, false); }
     else { if (collectStats) CRT_LAUNCH_S(1, true); else CRT_LAUNCH_S(1, false); }
 #undef CRT_LAUNCH_S
