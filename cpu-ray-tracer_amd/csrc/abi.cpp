@@ -18,7 +18,7 @@
 
 extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
-extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_whitted(const crt::Scene*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
@@ -271,7 +271,9 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     const uint64_t leafOffB = pairBytes, leafBytes = (nTris + 1) * 48;       // +1: record fetches read 64 B from a 48-B LeafTri
     const uint64_t tlasOffB = (leafOffB + leafBytes + 63) & ~63ull;
     const uint64_t tlasBytes = (sd->kind == CRT_SCENE_TLAS) ? (uint64_t)sd->tlasNodeCount * 32 : 0;
-    const uint64_t instOffB = (tlasOffB + tlasBytes + 127) & ~127ull;
+    const uint64_t tlasPairOffB = (tlasOffB + tlasBytes + 63) & ~63ull;      // one NodePair-shaped record per TLAS interior node (at most tlasNodeCount / 2)
+    const uint64_t tlasPairBytes = (sd->kind == CRT_SCENE_TLAS) ? (uint64_t)sd->tlasNodeCount * 32 : 0;
+    const uint64_t instOffB = (tlasPairOffB + tlasPairBytes + 127) & ~127ull;
     const uint64_t instBytes = (sd->kind == CRT_SCENE_TLAS) ? (uint64_t)sd->bvhCount * 128 : 0;
     const uint64_t shadeOffB = (instOffB + instBytes + 63) & ~63ull;
     const uint64_t total = shadeOffB + nTris * 64;
@@ -282,10 +284,12 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     crt::NodePair* pairs = reinterpret_cast<crt::NodePair*>(geom.data());
     crt::LeafTri* leaf = reinterpret_cast<crt::LeafTri*>(geom.data() + leafOffB);
     crt::TlasNode* tlas = reinterpret_cast<crt::TlasNode*>(geom.data() + tlasOffB);
+    crt::NodePair* tlasPairs = reinterpret_cast<crt::NodePair*>(geom.data() + tlasPairOffB);
+    bool ref16ok = nPairs <= crt::kRef16MaxIndex && nTris < crt::kRef16MaxIndex;
     crt::Instance* inst = reinterpret_cast<crt::Instance*>(geom.data() + instOffB);
     crt::ShadeTri* shade = reinterpret_cast<crt::ShadeTri*>(geom.data() + shadeOffB);
 
-    uint64_t pairBase = 0, triBase = 0; uint32_t rootRef0 = 0;
+    uint64_t pairBase = 0, triBase = 0; uint32_t rootRef0 = 0, rootRef0_16 = 0;
     for (uint32_t bi = 0; bi < sd->bvhCount; bi++) {
         const crt_bvh& b = sd->bvhs[bi];
         // packed reference of node n (layout.h): interior -> offset of its child pair, leaf -> offset of its first LeafTri, both in 16-byte units
@@ -300,6 +304,12 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
             }
             return 0;
         };
+        // the same reference in 16 bits (layout.h): record INDEX instead of offset; only meaningful when ref16ok
+        auto ref16_of = [&](uint32_t n) -> uint32_t {
+            const crt_bvh_node& nd = b.nodes[n];
+            if (nd.triCount > 0) return (uint32_t)((triBase + nd.leftFirst + 1) & crt::kRef16IndexMask);
+            return crt::kRef16Interior | (uint32_t)((pairBase + ((nd.leftFirst - 1u) >> 1)) & crt::kRef16IndexMask);
+        };
         int r;
         for (uint32_t n = 1; n + 1 < b.nodesUsed; n += 2) {
             crt::NodePair& p = pairs[pairBase + ((n - 1) >> 1)];
@@ -307,9 +317,11 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
                 const crt_bvh_node& nd = b.nodes[n + k];
                 memcpy(p.c[k].lo, nd.aabbMin, 12); memcpy(p.c[k].hi, nd.aabbMax, 12);
                 if ((r = ref_of(n + k, &p.c[k].ref))) return r;
+                p.c[k].ref16 = ref16_of(n + k);
             }
         }
         uint32_t rootRef = 0; if ((r = ref_of(0, &rootRef))) return r;
+        const uint32_t rootRef16 = ref16_of(0);
         // `remain` of every leaf slot: triangles left in its leaf including itself
         std::vector<uint32_t> remain(b.triCount, 1u);
         for (uint32_t n = 0; n < b.nodesUsed; n++) {
@@ -340,18 +352,20 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         if (sd->kind == CRT_SCENE_TLAS) {
             crt::Instance& in = inst[bi];
             memcpy(in.invT, b.invT, 48); memcpy(in.T, b.T, 48);
-            in.shadeBase = (uint32_t)triBase; in.mat = 2 + b.matIdx; in.rootRef = rootRef; in.objIdx = b.objIdx;
-        } else rootRef0 = rootRef;
+            in.shadeBase = (uint32_t)triBase; in.rootRef16 = rootRef16; in.rootRef = rootRef; in.objIdx = b.objIdx;
+        } else { rootRef0 = rootRef; rootRef0_16 = rootRef16; }
         pairBase += b.nodesUsed / 2; triBase += b.triCount;
     }
     leaf[nTris].remain = 1;                                                 // pad record
-    uint32_t tlasHeight = 0, tlasRoot = 0;
+    uint32_t tlasHeight = 0, tlasRoot = 0, tlasRoot16 = 0;
     if (sd->kind == CRT_SCENE_TLAS) {
+        uint32_t nTlasPairs = 0;
         for (uint32_t i = 0; i < sd->tlasNodeCount; i++) {      // device copy carries each node's packed reference instead of leftRight / BLAS
             const crt_tlas_node& nd = sd->tlasNodes[i];
-            memcpy(tlas[i].lo, nd.aabbMin, 12); memcpy(tlas[i].hi, nd.aabbMax, 12); tlas[i].pad = 0;
+            memcpy(tlas[i].lo, nd.aabbMin, 12); memcpy(tlas[i].hi, nd.aabbMax, 12);
             tlas[i].ref = nd.leftRight ? (crt::kRefTlasInterior | (nd.leftRight & 0x7fffu) | (((nd.leftRight >> 16) & 0x7fffu) << 15))
                                        : (crt::kRefTlasLeaf | (nd.BLAS & 0xffffu));
+            tlas[i].ref16 = nd.leftRight ? (crt::kRef16TlasBit | nTlasPairs++) : (crt::kRef16TlasLeaf | (nd.BLAS & crt::kRef16IndexMask));   // interior nodes number their child pairs
         }
         std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 0u}); size_t visited = 0;
         while (!st.empty()) {
@@ -363,7 +377,14 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
             if (l >= sd->tlasNodeCount || r >= sd->tlasNodeCount) return c->fail(CRT_ERR_INVALID, "TLAS child index out of range");
             st.push_back({l, d + 1}); st.push_back({r, d + 1});
         }
-        tlasRoot = tlas[0].ref;
+        // the child pair of every TLAS interior node, side by side in the NodePair layout (render_pool_kernel fetches it with one 64-byte record load)
+        for (uint32_t i = 0; i < sd->tlasNodeCount; i++) {
+            const crt_tlas_node& nd = sd->tlasNodes[i];
+            if (nd.leftRight == 0) continue;
+            crt::NodePair& p = tlasPairs[tlas[i].ref16 & crt::kRef16IndexMask];
+            memcpy(&p.c[0], &tlas[nd.leftRight & 0xffffu], 32); memcpy(&p.c[1], &tlas[nd.leftRight >> 16], 32);
+        }
+        tlasRoot = tlas[0].ref; tlasRoot16 = tlas[0].ref16;
     }
     // texel pool + materials ([0] light, [1] floor, then the scene's — file_scene.cpp:10-12, 30-38); each carries its texture descriptor
     std::vector<uint32_t> texOff(sd->textureCount); uint64_t texels = 0;
@@ -424,6 +445,9 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     if ((r = upload(c, geom, &dGeom))) return r;
     s.geom = dGeom;
     s.tlasOff = (uint32_t)tlasOffB; s.instOff = (uint32_t)instOffB; s.shadeOff = (uint32_t)shadeOffB;
+    s.leafOff = (uint32_t)leafOffB; s.tlasPairOff = (uint32_t)tlasPairOffB;
+    s.rootRef16 = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot16 : rootRef0_16;
+    s.ref16ok = (ref16ok && !getenv("CRT_DEBUG_NO_REF16")) ? 1u : 0u;
     if ((r = upload(c, mats, &s.mats))) return r;
     s.rootRef = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot : rootRef0;
     // Traversal stack entries (LDS is what limits the waves per SIMD, so no slack): the ordered traversal keeps at most one pending sibling per level
@@ -630,9 +654,9 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         EventPair ev;
         if ((r = take_event(c, c->evRender, &ev))) return r;
         HIPCK(c, hipEventRecord(ev.a, st));
-        if (c->usePool)
+        if (c->usePool && c->hScene.ref16ok)
             HIPCK(c, crt_launch_render_pool(&c->hScene, slab, (char*)slab + (size_t)((nf + 63u) / 64u) * sample_bytes_per_window(c, passes), c->dCounters, c->dTileClocks, c->dTileOrder,
-                                            c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, st));
+                                            c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->cfg.collectStats, st));
         else
             HIPCK(c, crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
                                        spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, st));

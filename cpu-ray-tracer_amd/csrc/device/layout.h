@@ -5,7 +5,8 @@
 // aligned for 16-byte vector loads (global_load_dwordx4); a traversal step always fetches the 64 bytes at its record.
 //   NodePair  64 B  both children of an interior node in one aligned 64-byte line
 //   LeafTri   48 B  Möller–Trumbore operands in leaf order (the triangleIndices indirection is resolved at upload)
-//   TlasNode  32 B  reference TLASBVHNode layout, leftRight/BLAS replaced by the node's packed reference
+//   TlasNode  32 B  reference TLASBVHNode layout, leftRight/BLAS replaced by the node's packed reference; the TLAS child pairs section holds, for every
+//                   TLAS interior node, its two child TlasNodes side by side (NodePair layout)
 //   Instance 128 B  per-BLAS: invT rows + ids in the first 64 B (what entering the BLAS needs), then T rows
 //   ShadeTri  64 B  normals + uvs + material of a triangle, addressed by the global shade index carried in LeafTri
 #pragma once
@@ -27,7 +28,17 @@ constexpr uint32_t kRefDone = 0u;
 constexpr uint32_t kRefOffsetMask = 0x3fffffffu;
 constexpr uint64_t kMaxGeomBytes = 1ull << 32;     // 32-bit byte offsets
 
-struct alignas(16) NodeChild { float lo[3]; uint32_t ref; float hi[3]; uint32_t pad; };   // 32 B
+// 16-bit form of the same reference (`ref16`), used by render_pool_kernel for `cur` and for its traversal stack (2 bytes per entry: LDS is
+// what limits the waves per SIMD): the same tags in bits 15..14 and a record INDEX in bits 13..0 instead of an offset
+//   10 : BVH / BLAS interior, index of its NodePair                 (record at            index * 64)
+//   00 : BVH / BLAS leaf,     index of its first LeafTri + 1; 0 = "traversal done"   (record at leafOff + (index - 1) * 48; the next triangle of the leaf is ref16 + 1)
+//   01 : TLAS interior,       index of its TLAS child pair         (record at tlasPairOff + index * 64)
+//   11 : TLAS leaf,           BLAS (Instance) index                (record at instOff + index * 128);  0xFFFF = "return to TLAS level" marker
+// Scene::ref16ok tells whether the scene fits (<= 16383 node pairs and < 16383 triangles over all BVHs); otherwise the host launches render_tiles_kernel.
+constexpr uint32_t kRef16Interior = 0x8000u, kRef16TlasBit = 0x4000u, kRef16TlasLeaf = 0xC000u, kRef16TagMask = 0xC000u, kRef16IndexMask = 0x3fffu;
+constexpr uint32_t kRef16Return = 0xFFFFu, kRef16MaxIndex = 0x3ffeu;
+
+struct alignas(16) NodeChild { float lo[3]; uint32_t ref; float hi[3]; uint32_t ref16; };   // 32 B; ref / ref16 = the child's packed reference, 32- and 16-bit form
 struct alignas(64) NodePair { NodeChild c[2]; };                                           // 64 B
 
 struct alignas(16) LeafTri {              // 48 B = 3 offset units
@@ -42,12 +53,12 @@ struct alignas(16) ShadeTri {             // 64 B
     int32_t mat;                          // index into Scene::mats ([0] light, [1] floor, 2.. scene materials)
 };
 
-struct alignas(16) TlasNode { float lo[3]; uint32_t ref; float hi[3]; uint32_t pad; };         // 32 B; ref = packed reference of THIS node
+struct alignas(16) TlasNode { float lo[3]; uint32_t ref; float hi[3]; uint32_t ref16; };       // 32 B; ref / ref16 = packed reference of THIS node
 
 struct alignas(16) Instance {             // 128 B
     float invT[12];                       // rows 0..2 of BLASBVH::invT (ray -> object space)
     uint32_t shadeBase;                   // first ShadeTri of this BLAS (find_nearest reports triIdx = shadeIdx - shadeBase)
-    int32_t mat;
+    uint32_t rootRef16;                   // 16-bit reference of the BLAS's node 0
     uint32_t rootRef;                     // packed reference of the BLAS's node 0
     int32_t objIdx;
     float T[12];                          // rows 0..2 of BLASBVH::T    (normal -> world space)
@@ -77,6 +88,8 @@ struct Scene {                            // passed to the kernels BY VALUE (ker
     // pools
     const char* geom;                     // pairs | leaf tris | TLAS nodes | instances | shade records
     uint32_t tlasOff, instOff, shadeOff;  // byte offsets of those sections inside geom
+    uint32_t leafOff, tlasPairOff;        // ... of the leaf triangles and of the TLAS child pairs (NodePair layout: the two child TlasNodes of every TLAS interior node side by side)
+    uint32_t rootRef16, ref16ok;          // 16-bit form of rootRef; 1: every reference of the scene has a 16-bit form (render_pool_kernel can run)
     const uint32_t* texels;
     const Material* mats;
     uint32_t rootRef;                     // packed reference of the root (BVH node 0 / TLAS node 0)

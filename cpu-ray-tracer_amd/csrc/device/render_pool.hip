@@ -69,8 +69,10 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
     const char* __restrict__ geom = sc.geom;
     float* __restrict__ fac = facScratch + (size_t)blockIdx.x * (15u * (uint32_t)S);
 
-    uint32_t* stk = lds + lane;                                                  // traversal stack of the stream resident in this lane: entry i at stk[i * 64]
-    uint32_t* st = lds + sc.stackDepth * 64u;                                    // parked stream state
+    // `cur` and the stack entries of this kernel are 16-bit references (layout.h: ref16 — the children's are stored next to the 32-bit ones in
+    // every NodePair); 2 bytes per stack entry instead of 4 is what lets 128 parked streams + the stacks fit 4 waves per SIMD
+    uint16_t* stk = reinterpret_cast<uint16_t*>(lds) + lane;                     // traversal stack of the stream resident in this lane: entry i at stk[i * 64]
+    uint32_t* st = lds + sc.stackDepth * 32u;                                    // parked stream state (behind stackDepth * 64 two-byte entries)
     float* stf = reinterpret_cast<float*>(st);
     uint8_t* qEnd = reinterpret_cast<uint8_t*>(st + F_COUNT * S);
     uint8_t* qBnc = qEnd + 128, * qRdy = qEnd + 256;
@@ -123,13 +125,13 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
                 else { d1 = box_exact(a0, a1, O, rD, nh.t); d2 = box_exact(b0, b1, O, rD, nh.t); }
                 const bool sw = d1 > d2;
                 const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
-                const uint32_t rn = sw ? asu(b0.w) : asu(a0.w), rf = sw ? asu(a0.w) : asu(b0.w);
+                const uint32_t rn = sw ? asu(b1.w) : asu(a1.w), rf = sw ? asu(a1.w) : asu(b1.w);   // the children's ref16
                 const bool hitN = dn != 1e30f;
                 pend = (hitN && df != 1e30f) ? rf : 0u;
                 ncur = hitN ? rn : kRefDone;
                 if (COUNT) { if (KIND == 0) cn.interior++; else cn.tlas++; }
-            } else ncur = sc.rootRef;
-            if (COUNT && KIND == 0 && (ncur & 0xC0000000u) == 0u && ncur != kRefDone) cn.leaf++;
+            } else ncur = sc.rootRef16;
+            if (COUNT && KIND == 0 && (ncur & kRef16TagMask) == 0u && ncur != kRefDone) cn.leaf++;
             stf[F_OX * S + s] = O.x; stf[F_OY * S + s] = O.y; stf[F_OZ * S + s] = O.z;
             stf[F_DX * S + s] = D.x; stf[F_DY * S + s] = D.y; stf[F_DZ * S + s] = D.z;
             stf[F_RX * S + s] = rD.x; stf[F_RY * S + s] = rD.y; stf[F_RZ * S + s] = rD.z;
@@ -151,9 +153,9 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
 
     for (;;) {
         // ---------------- D. walk: state ballots of the resident streams, then the phases that have lanes ------------------------------
-        const bool isNode = res && (KIND == 1 ? (((cur >> 31) ^ (cur >> 30)) & 1u) != 0u : (cur & 0xC0000000u) == kRefInterior);
-        const bool isTri = res && cur != kRefDone && (cur & 0xC0000000u) == 0u;
-        const bool isTlas = (KIND == 1) && res && (cur & 0xC0000000u) == kRefTlasLeaf;
+        const bool isNode = res && (KIND == 1 ? (((cur >> 15) ^ (cur >> 14)) & 1u) != 0u : (cur & kRef16TagMask) == kRef16Interior);
+        const bool isTri = res && cur != kRefDone && (cur & kRef16TagMask) == 0u;
+        const bool isTlas = (KIND == 1) && res && (cur & kRef16TagMask) == kRef16TlasLeaf;
         const bool runNode = __builtin_amdgcn_ballot_w64(isNode) != 0ull, runTri = __builtin_amdgcn_ballot_w64(isTri) != 0ull;
         const bool runTlas = (KIND == 1) && __builtin_amdgcn_ballot_w64(isTlas) != 0ull;
         // The record loads issued at the end of the previous trip are first needed here.  Naming all four tuples in one
@@ -167,29 +169,29 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
             const f3 D = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
             to_object_space(q0, q1, q2, O, D, tO, tD, trD);
             rayFinite = finite3(trD);
-            stk[sp * 64u] = kRefReturn; sp++;
-            const uint32_t next = asu(q3.z);                                       // Instance::rootRef
-            if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+            stk[sp * 64u] = (uint16_t)kRef16Return; sp++;
+            const uint32_t next = asu(q3.y);                                       // Instance::rootRef16
+            if (COUNT && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
             cur = next;
         }
         if (runNode) {
             // ---------------- NODE phase (infra/bvh.cpp:244-257) ------------------------------------------------------------------------
             const bool allFinite = __builtin_amdgcn_ballot_w64(isNode && !rayFinite) == 0ull;
             if (isNode) {
-                if (COUNT) { if (KIND == 1 && (cur & kRefTlasBit) != 0u) cn.tlas++; else cn.interior++; }
+                if (COUNT) { if (KIND == 1 && (cur & kRef16TlasBit) != 0u) cn.tlas++; else cn.interior++; }
                 uint32_t top = CRT_TOP();                                          // speculative: lands during the slab arithmetic
                 float d1, d2;
                 if (allFinite) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
                 else { d1 = box_exact(q0, q1, tO, trD, h.t); d2 = box_exact(q2, q3, tO, trD, h.t); }
                 const bool sw = d1 > d2;                                           // near child first (strict >: ties keep child 1)
                 const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
-                const uint32_t rn = sw ? asu(q2.w) : asu(q0.w), rf = sw ? asu(q0.w) : asu(q2.w);
-                stk[sp * 64u] = rf;                                                // dead store unless `push`
+                const uint32_t rn = sw ? asu(q3.w) : asu(q1.w), rf = sw ? asu(q1.w) : asu(q3.w);   // the children's ref16
+                stk[sp * 64u] = (uint16_t)rf;                                      // dead store unless `push`
                 const bool hitN = dn != 1e30f, push = hitN && df != 1e30f;
                 bool pop = !hitN && sp != 0u;
                 uint32_t next = hitN ? rn : (pop ? top : kRefDone);
                 sp = sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
-                if (KIND == 1 && next == kRefReturn) {                             // BLAS finished: back to the world-space ray, pop the TLAS entry below
+                if (KIND == 1 && next == kRef16Return) {                             // BLAS finished: back to the world-space ray, pop the TLAS entry below
                     tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
                     tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
                     trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
                     pop = sp != 0u; top = CRT_TOP();
                     next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
                 }
-                if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+                if (COUNT && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
                 cur = next;
             }
         }
@@ -208,9 +210,9 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
             hit_tri(q0, q1, q2, tO, tD, h);
             const bool more = asu(q2.w) > 1u;                                      // next LeafTri of this leaf (48 B = 3 units)
             bool pop = !more && sp != 0u;
-            uint32_t next = more ? cur + 3u : (pop ? top : kRefDone);
+            uint32_t next = more ? cur + 1u : (pop ? top : kRefDone);     // the leaf's next LeafTri is the next index
             sp -= pop ? 1u : 0u;
-            if (KIND == 1 && next == kRefReturn) {
+            if (KIND == 1 && next == kRef16Return) {
                 tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
                 tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
                 trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
                 pop = sp != 0u; top = CRT_TOP();
                 next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
             }
-            if (COUNT && !more && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+            if (COUNT && !more && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
             cur = next;
         }
         asm volatile("" ::: "memory");
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
                     h.t = stf[F_T * S + sid]; h.objIdx = (int)(st[F_META * S + sid] >> kMetaObjShift) - 1; h.u = 0; h.v = 0; h.triIdx = -1;
                     cur = st[F_CUR * S + sid];
                     const uint32_t pend = st[F_PEND * S + sid];
-                    stk[0] = pend; sp = pend ? 1u : 0u;                            // a dead store unless the far root child was hit
+                    stk[0] = (uint16_t)pend; sp = pend ? 1u : 0u;                            // a dead store unless the far root child was hit
                     rayFinite = finite3(trD);
                     res = true;
                 }
@@ -276,12 +278,12 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
         // ---------------- E. issue the record loads of the resident streams (consumed by the next trip) ----------------------------------
         {
             const bool want = res && cur != kRefDone;
-            uint32_t oa = (cur & kRefOffsetMask) << 4;                             // NodePair / LeafTri
+            // record offset of a 16-bit reference: index * record size + section base (layout.h)
+            const uint32_t idx = cur & kRef16IndexMask;
+            uint32_t oa = (cur & kRef16Interior) ? idx * 64u : sc.leafOff - 48u + idx * 48u;     // NodePair | LeafTri
+            if (KIND == 1 && (cur & kRef16TlasBit) != 0u)
+                oa = (cur & kRef16Interior) ? sc.instOff + idx * 128u : sc.tlasPairOff + idx * 64u;   // TLAS leaf: Instance {invT rows, ids} | TLAS interior: its child pair
             uint32_t ob = oa + 32u;
-            if (KIND == 1 && (cur & kRefTlasBit) != 0u) {
-                if (cur & kRefInterior) { oa = sc.instOff + (cur & 0xffffu) * 128u; ob = oa + 32u; }                // TLAS leaf: Instance {invT rows, ids}
-                else { oa = sc.tlasOff + (cur & 0x7fffu) * 32u; ob = sc.tlasOff + ((cur >> 15) & 0x7fffu) * 32u; } // TLAS interior: the two child nodes
-            }
             if (!want) { oa = 0u; ob = 32u; }
             if (__builtin_amdgcn_ballot_w64(want) != 0ull) { q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, ob); q3 = ldg(geom, ob + 16u); }
         }
@@ -479,21 +481,22 @@ __global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, floa
 #define CRT_POOL_STREAMS 128
 #endif
 extern "C" uint32_t crt_pool_streams(uint32_t frames) { return frames > 64u ? (uint32_t)CRT_POOL_STREAMS : 64u; }
-extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackBytes, uint32_t streams) { return stackBytes + crt::F_COUNT * streams * 4u + 3u * 128u; }
+extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackDepth, uint32_t streams) { return stackDepth * 64u * 2u + crt::F_COUNT * streams * 4u + 3u * 128u; }
 // bytes of throughput-factor scratch a launch of `windows` 64-frame windows needs behind its sample slab (15 floats per stream; a wave's
 // group of streams may reach past the last window, hence 128 stream slots per window)
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t tileCount) { return (size_t)tileCount * 128u * 15u * 4u; }
 
 extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, void* facScratch, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
-                                             uint32_t frames, uint32_t passes, uint32_t stackBytes, int collectStats, hipStream_t stream)
+                                             uint32_t frames, uint32_t passes, int collectStats, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
+    if (!sc->ref16ok) return hipErrorInvalidValue;                              // the host launches render_tiles_kernel for such scenes
     const uint32_t S = crt_pool_streams(frames);
     const uint32_t groups = (frames + S - 1u) / S;
     if ((unsigned long long)tileCount * groups > 0x7fffffffull) return hipErrorInvalidValue;
     dim3 grid(tileCount * groups), block(64);
-    const uint32_t ldsBytes = crt_pool_lds_bytes(stackBytes, S);
+    const uint32_t ldsBytes = crt_pool_lds_bytes(sc->stackDepth, S);
 #define CRT_LAUNCH(K, C, SS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups)
 #define CRT_LAUNCH_S(K, C) do { if (S == 64u) CRT_LAUNCH(K, C, 64); else CRT_LAUNCH(K, C, CRT_POOL_STREAMS); } while (0)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH_S(0, true); else CRT_LAUNCH_S(0, false); }
