@@ -654,7 +654,8 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         EventPair ev;
         if ((r = take_event(c, c->evRender, &ev))) return r;
         HIPCK(c, hipEventRecord(ev.a, st));
-        if (c->usePool && c->hScene.ref16ok)
+        // the stream pool needs more streams than lanes to pay off: launches of <= 64 frames (one stream per lane) run render_tiles_kernel
+        if (c->usePool && c->hScene.ref16ok && nf > 64u)
             HIPCK(c, crt_launch_render_pool(&c->hScene, slab, (char*)slab + (size_t)((nf + 63u) / 64u) * sample_bytes_per_window(c, passes), c->dCounters, c->dTileClocks, c->dTileOrder,
                                             c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->cfg.collectStats, st));
         else

@@ -42,6 +42,9 @@ enum : uint32_t {
 constexpr uint32_t kMetaItemMask = 0x7ffu, kMetaDepthShift = 11u, kMetaInside = 1u << 14, kMetaFresh = 1u << 15, kMetaObjShift = 16u, kMetaLowMask = 0xffffu;
 constexpr uint32_t kQueueMask = 127u;                            // queues are rings of 128 one-byte stream ids (S <= 128)
 
+#ifndef CRT_POOL_MIN_WAVES
+#define CRT_POOL_MIN_WAVES 4         // waves per SIMD the register budget must allow (<= 128 VGPRs)
+#endif
 #ifndef CRT_POOL_SHADE_MIN
 #define CRT_POOL_SHADE_MIN 64     // streams a shading pass waits for ...
 #endif
@@ -50,7 +53,7 @@ constexpr uint32_t kQueueMask = 127u;                            // queues are r
 #endif
 
 template <int KIND, bool COUNT, int S>
-__global__ __launch_bounds__(64, 4) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
+__global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
                                                              unsigned long long* __restrict__ tileClocks, const uint32_t* __restrict__ tileOrder,
                                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                              uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t groups)
