@@ -63,12 +63,16 @@ struct crt_ctx {
     // dispatch-order heuristic: owned tiles that can see the scene's meshes come first (see render_tiles_kernel)
     float meshLo[3] = {0, 0, 0}, meshHi[3] = {0, 0, 0}; bool orderDirty = true;
     uint32_t* dTileOrder = nullptr;
+    uint32_t* hTileOrder[2] = {nullptr, nullptr}; hipEvent_t orderCopied[2] = {nullptr, nullptr}; hipEvent_t orderReady = nullptr; int orderFlip = 0;
     bool haveScene = false;
+    void* dQueryRays = nullptr; void* dQueryHits = nullptr; size_t queryCap = 0;      // crt_find_nearest staging (rays)
+    uint32_t poolMinFrames = 65;  // launches of fewer frames (one stream per lane) run render_tiles_kernel
     bool usePool = true;          // render_pool_kernel (stream pool); CRT_RENDER_KERNEL=tiles selects render_tiles_kernel (one stream per lane)
     uint32_t ldsBytes = 0;
     // timing of the last crt_render
     std::vector<EventPair> evPool; size_t evUsedRender = 0, evUsedAcc = 0;
-    std::vector<EventPair> evRender, evAcc;
+    std::deque<EventPair> evRender, evAcc;                        // launches not yet folded into the totals below (oldest first)
+    double foldedRenderMs = 0, foldedAccMs = 0; uint32_t foldedLaunches = 0;
 
     int fail(int code, const char* fmt, ...)
     {
@@ -156,12 +160,14 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     if (cfg->device < 0 || cfg->device >= ndev) { g_createError = "crt_create: device ordinal out of range"; return CRT_ERR_INVALID; }
     crt_ctx* c = new crt_ctx();
     c->cfg = *cfg;
-    if (const char* k = getenv("CRT_RENDER_KERNEL")) c->usePool = strcmp(k, "tiles") != 0;
+    if (const char* k = getenv("CRT_RENDER_KERNEL")) {             // tests / A-B runs: "tiles" = never the stream pool, "pool_always" = also for launches of <= 64 frames
+        c->usePool = strcmp(k, "tiles") != 0;
+        if (!strcmp(k, "pool_always")) c->poolMinFrames = 1;
+    }
     if (c->cfg.depthLimit < 0) c->cfg.depthLimit = 5;
     if (c->cfg.depthLimit > 5) { g_createError = "crt_create: depthLimit > 5 unsupported (throughput stack holds 5 factors; reference default is 5)"; delete c; return CRT_ERR_UNSUPPORTED; }
-    if (c->cfg.maxFramesPerLaunch <= 0) c->cfg.maxFramesPerLaunch = 4096;                     // 64 windows of 64 frames
+    if (c->cfg.maxFramesPerLaunch <= 0) c->cfg.maxFramesPerLaunch = c->cfg.collectStats ? 64 : 4096;   // 64 windows of 64 frames; per-tile clocks of a statistics context describe ONE window
     if (c->cfg.maxFramesPerLaunch > 64) c->cfg.maxFramesPerLaunch = c->cfg.maxFramesPerLaunch / 64 * 64;   // whole windows (< 64: one partial window per launch)
-    if (c->cfg.collectStats) c->cfg.maxFramesPerLaunch = 64;                                  // per-tile clocks describe ONE window
     if (c->cfg.renderStreams < 0) c->cfg.renderStreams = 0;
     c->tilesX = cfg->width / 16; c->tilesY = cfg->height / 16;      // truncating, as renderer.cpp:151
     const int tiles = c->tilesX * c->tilesY;
@@ -215,6 +221,8 @@ void crt_destroy(crt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->freeScene();
     for (auto& ev : c->evPool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto& ev : c->evRender) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto& ev : c->evAcc) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (c->dAccOwned) (void)hipFree(c->dAccOwned);
     for (auto st : c->streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto& r : c->inflight) (void)hipEventDestroy(r.freed);
@@ -227,6 +235,9 @@ void crt_destroy(crt_ctx* c)
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->dTileClocks) (void)hipFree(c->dTileClocks);
     if (c->dTileOrder) (void)hipFree(c->dTileOrder);
+    if (c->dQueryRays) (void)hipFree(c->dQueryRays);
+    if (c->dQueryHits) (void)hipFree(c->dQueryHits);
+    for (int k = 0; k < 2; k++) { if (c->hTileOrder[k]) (void)hipHostFree(c->hTileOrder[k]); if (c->orderCopied[k]) (void)hipEventDestroy(c->orderCopied[k]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -245,6 +256,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         return c->fail(CRT_ERR_INVALID, "floor/sky texture index out of range");
     for (uint32_t i = 0; i < sd->textureCount; i++)
         if (!sd->textures[i].pixels || sd->textures[i].width <= 0 || sd->textures[i].height <= 0) return c->fail(CRT_ERR_INVALID, "texture %u is empty", i);
+    if (sd->materialCount > 0 && !sd->materials) return c->fail(CRT_ERR_INVALID, "materialCount is %u but materials is NULL", sd->materialCount);
     for (uint32_t i = 0; i < sd->materialCount; i++)
         if (sd->materials[i].texture >= (int)sd->textureCount) return c->fail(CRT_ERR_INVALID, "material %u: texture index out of range", i);
     if (sd->kind == CRT_SCENE_FILE) {
@@ -343,6 +355,8 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         }
         for (uint32_t ti = 0; ti < b.triCount; ti++) {                    // shading records in the reference's triIdx order
             const crt_tri& t = b.triangles[ti];
+            if (sd->kind == CRT_SCENE_FILE && (t.objIdx < 2 || (uint32_t)(t.objIdx - 2) >= sd->objCount))   // every triangle, not only those triangleIndices reaches
+                return c->fail(CRT_ERR_INVALID, "triangle %u: objIdx %d has no entry in objMatIdx", ti, t.objIdx);
             crt::ShadeTri& s = shade[triBase + ti];
             memcpy(s.n0, t.normal0, 12); memcpy(s.n1, t.normal1, 12); memcpy(s.n2, t.normal2, 12);
             memcpy(s.uv0, t.uv0, 8); memcpy(s.uv1, t.uv1, 8); memcpy(s.uv2, t.uv2, 8);
@@ -486,7 +500,9 @@ int crt_set_camera(crt_ctx* c, const float camPos[3], const float tl[3], const f
 {
     if (!c || !camPos || !tl || !tr || !bl) return CRT_ERR_INVALID;
     HIPCK(c, hipSetDevice(c->cfg.device));
-    memcpy(c->hScene.camPos, camPos, 12); memcpy(c->hScene.topLeft, tl, 12); memcpy(c->hScene.topRight, tr, 12); memcpy(c->hScene.bottomLeft, bl, 12);
+    crt::Scene& s = c->hScene;
+    if (!memcmp(s.camPos, camPos, 12) && !memcmp(s.topLeft, tl, 12) && !memcmp(s.topRight, tr, 12) && !memcmp(s.bottomLeft, bl, 12)) return CRT_OK;   // unchanged (a per-frame PushCamera)
+    memcpy(s.camPos, camPos, 12); memcpy(s.topLeft, tl, 12); memcpy(s.topRight, tr, 12); memcpy(s.bottomLeft, bl, 12);
     c->orderDirty = true;
     return CRT_OK;      // the Scene block travels by value in every launch's kernel arguments
 }
@@ -527,10 +543,19 @@ static int update_tile_order(crt_ctx* c)
         ((tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) ? first : rest).push_back(i);
     }
     first.insert(first.end(), rest.begin(), rest.end());
+    // No host synchronisation: the copy runs on the main stream, which is ordered behind every render launch submitted so far (it waits for
+    // each launch's end event before that launch's accumulate), so the previous order is no longer read when it is overwritten; later
+    // launches wait for `orderReady` on their own stream.  The staging buffers are pinned and alternate; one is reused only after its own copy.
     if (!c->dTileOrder) HIPCK(c, hipMalloc((void**)&c->dTileOrder, (size_t)c->tileCount * 4));
-    HIPCK(c, hipStreamSynchronize(c->stream));              // launches in flight still read the previous order
-    for (auto st : c->streams) HIPCK(c, hipStreamSynchronize(st));
-    HIPCK(c, hipMemcpy(c->dTileOrder, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+    const int k = c->orderFlip ^= 1;
+    if (!c->hTileOrder[k]) {
+        HIPCK(c, hipHostMalloc((void**)&c->hTileOrder[k], (size_t)c->tileCount * 4, hipHostMallocDefault));
+        HIPCK(c, hipEventCreateWithFlags(&c->orderCopied[k], hipEventDisableTiming));
+    } else HIPCK(c, hipEventSynchronize(c->orderCopied[k]));
+    memcpy(c->hTileOrder[k], first.data(), first.size() * 4);
+    HIPCK(c, hipMemcpyAsync(c->dTileOrder, c->hTileOrder[k], first.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipEventRecord(c->orderCopied[k], c->stream));
+    c->orderReady = c->orderCopied[k];
     c->orderDirty = false;
     return 0;
 }
@@ -540,7 +565,19 @@ static int update_tile_order(crt_ctx* c)
 static size_t sample_bytes_per_window(const crt_ctx* c, uint32_t passes) { return (size_t)c->tileCount * 256u * 64u * passes * 16u; }
 static size_t window_bytes(const crt_ctx* c, uint32_t passes) { return sample_bytes_per_window(c, passes) + (c->usePool ? crt_pool_scratch_bytes_per_window(c->tileCount) : 0); }
 
-static int take_event(crt_ctx* c, std::vector<EventPair>& list, EventPair* out)
+// Timing pairs of launches that have completed are folded into running totals and recycled, so a host that renders forever and never
+// asks for the timing (an interactive Tick loop) keeps a bounded number of HIP events alive.
+static void fold_completed(crt_ctx* c, std::deque<EventPair>& list, double* ms, uint32_t* count)
+{
+    while (list.size() > 64 && hipEventQuery(list.front().b) == hipSuccess) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, list.front().a, list.front().b) == hipSuccess) *ms += t;
+        if (count) (*count)++;
+        c->evPool.push_back(list.front()); list.pop_front();
+    }
+}
+
+static int take_event(crt_ctx* c, std::deque<EventPair>& list, EventPair* out)
 {
     EventPair ev;
     if (c->evPool.empty()) {
@@ -650,12 +687,14 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         hipStream_t st = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
         size_t off = 0; int r;
         if ((r = take_region(c, (size_t)((nf + 63u) / 64u) * windowBytes, st, &off))) return r;
+        if (c->orderReady) HIPCK(c, hipStreamWaitEvent(st, c->orderReady, 0));
         void* slab = c->pool + off;
         EventPair ev;
+        fold_completed(c, c->evRender, &c->foldedRenderMs, &c->foldedLaunches); fold_completed(c, c->evAcc, &c->foldedAccMs, nullptr);
         if ((r = take_event(c, c->evRender, &ev))) return r;
         HIPCK(c, hipEventRecord(ev.a, st));
         // the stream pool needs more streams than lanes to pay off: launches of <= 64 frames (one stream per lane) run render_tiles_kernel
-        if (c->usePool && c->hScene.ref16ok && nf > 64u)
+        if (c->usePool && c->hScene.ref16ok && nf >= c->poolMinFrames)
             HIPCK(c, crt_launch_render_pool(&c->hScene, slab, (char*)slab + (size_t)((nf + 63u) / 64u) * sample_bytes_per_window(c, passes), c->dCounters, c->dTileClocks, c->dTileOrder,
                                             c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->cfg.collectStats, st));
         else
@@ -735,19 +774,22 @@ int crt_find_nearest(crt_ctx* c, const crt_ray* rays, crt_hit* hits, size_t n)
     if (n == 0) return CRT_OK;
     if (n > 0x7fffffffull) return c->fail(CRT_ERR_UNSUPPORTED, "at most 2^31-1 rays per call");
     HIPCK(c, hipSetDevice(c->cfg.device));
-    void *dR = nullptr, *dH = nullptr;
-    HIPCK(c, hipMalloc(&dR, n * sizeof(crt_ray)));
-    hipError_t e = hipMalloc(&dH, n * sizeof(crt_hit));
-    if (e != hipSuccess) { (void)hipFree(dR); return c->hip(e, "hipMalloc(hits)"); }
-    int rc = CRT_OK;
-    do {
-        if ((e = hipMemcpyAsync(dR, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, c->stream)) != hipSuccess) { rc = c->hip(e, "copy rays"); break; }
-        if ((e = crt_launch_find_nearest(&c->hScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->stream)) != hipSuccess) { rc = c->hip(e, "launch find_nearest"); break; }
-        if ((e = hipMemcpyAsync(hits, dH, n * sizeof(crt_hit), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) { rc = c->hip(e, "copy hits"); break; }
-        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { rc = c->hip(e, "sync"); break; }
-    } while (0);
-    (void)hipFree(dR); (void)hipFree(dH);
-    return rc;
+    // query buffers are kept and grown to the high-water mark (hipMalloc synchronises the device)
+    if (n > c->queryCap) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (c->dQueryRays) (void)hipFree(c->dQueryRays);
+        if (c->dQueryHits) (void)hipFree(c->dQueryHits);
+        c->dQueryRays = c->dQueryHits = nullptr; c->queryCap = 0;
+        HIPCK(c, hipMalloc(&c->dQueryRays, n * sizeof(crt_ray)));
+        HIPCK(c, hipMalloc(&c->dQueryHits, n * sizeof(crt_hit)));
+        c->queryCap = n;
+    }
+    void *dR = c->dQueryRays, *dH = c->dQueryHits;
+    HIPCK(c, hipMemcpyAsync(dR, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, crt_launch_find_nearest(&c->hScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->stream));
+    HIPCK(c, hipMemcpyAsync(hits, dH, n * sizeof(crt_hit), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
 }
 
 int crt_get_counters(crt_ctx* c, crt_counters* out)
@@ -774,9 +816,11 @@ int crt_get_timing(crt_ctx* c, crt_timing* out)
     HIPCK(c, hipStreamSynchronize(c->stream));
     for (auto st : c->streams) HIPCK(c, hipStreamSynchronize(st));
     memset(out, 0, sizeof(*out));
+    out->render_kernel_ms = (float)c->foldedRenderMs; out->resolve_kernel_ms = (float)c->foldedAccMs;
     for (auto& ev : c->evRender) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->render_kernel_ms += ms; }
     for (auto& ev : c->evAcc) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->resolve_kernel_ms += ms; }
-    out->render_launches = (uint32_t)c->evRender.size();
+    out->render_launches = (uint32_t)c->evRender.size() + c->foldedLaunches;
+    c->foldedRenderMs = c->foldedAccMs = 0; c->foldedLaunches = 0;
     for (auto& ev : c->evRender) c->evPool.push_back(ev);      // the figures cover every launch since the previous crt_get_timing
     for (auto& ev : c->evAcc) c->evPool.push_back(ev);
     c->evRender.clear(); c->evAcc.clear();
@@ -794,6 +838,9 @@ int crt_get_tile_clocks(crt_ctx* c, uint64_t* out)
 }
 
 // diagnostic builds (-DCRT_STAMPS) only: 16 extra words per tile behind the tile clocks (not part of the public ABI)
+// tests: HIP timing events currently held by the context (bounded: completed launches are folded into totals, see fold_completed)
+extern "C" int crt_debug_live_events(crt_ctx* c) { return c ? (int)(2 * (c->evRender.size() + c->evAcc.size() + c->evPool.size())) : -1; }
+
 extern "C" int crt_debug_tile_stamps(crt_ctx* c, uint64_t* out)
 {
     if (!c || !out || !c->dTileClocks) return CRT_ERR_INVALID;

@@ -241,7 +241,7 @@ Raw decodePng(const std::string& d, const std::string& path)
         const uint32_t len = be32(p + o); const std::string typ((const char*)p + o + 4, 4);
         if (o + 12 + (size_t)len > size) fail(path + ": truncated PNG chunk");
         const uint8_t* body = p + o + 8;
-        if (typ == "IHDR") { w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; haveHdr = true; }
+        if (typ == "IHDR") { if (len != 13) fail(path + ": PNG IHDR chunk must hold 13 bytes"); w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; haveHdr = true; }
         else if (typ == "IDAT") idat.insert(idat.end(), body, body + len);
         else if (typ == "PLTE") plte.assign(body, body + len);
         else if (typ == "tRNS") trns.assign(body, body + len);
@@ -249,6 +249,7 @@ Raw decodePng(const std::string& d, const std::string& path)
         o += 12 + (size_t)len;
     }
     if (!haveHdr || w == 0 || h == 0) fail(path + ": bad PNG header");
+    if (w > (1u << 15) || h > (1u << 15)) fail(path + ": PNG larger than 32768 x 32768 is refused");     // stb_image's STBI_MAX_DIMENSIONS is 1 << 24; the texel pool addresses 2^32
     if (interlace) fail(path + ": interlaced PNG is not supported by this loader");
     int ch; switch (ctype) { case 0: ch = 1; break; case 2: ch = 3; break; case 3: ch = 1; break; case 4: ch = 2; break; case 6: ch = 4; break; default: fail(path + ": bad PNG colour type"); }
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) fail(path + ": unsupported PNG bit depth");

@@ -10,6 +10,15 @@ import pytest
 from conftest import ASSETS, GOLDEN, scene_path
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["default", "pool_always"])
+def render_kernel(request, monkeypatch):
+    """every test of this module runs twice: with the back end's default choice of render kernel (render_tiles_kernel for launches of
+    <= 64 frames, render_pool_kernel above) and with the stream-pool kernel forced for every launch size"""
+    if request.param != "default":
+        monkeypatch.setenv("CRT_RENDER_KERNEL", request.param)
+    return request.param
 G = json.load(open(os.path.join(GOLDEN, "golden.json")))
 
 

@@ -9,6 +9,15 @@ from conftest import ASSETS, scene_path
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["default", "pool_always"])
+def render_kernel(request, monkeypatch):
+    """every test of this module runs twice: with the back end's default choice of render kernel (render_tiles_kernel for launches of
+    <= 64 frames, render_pool_kernel above) and with the stream-pool kernel forced for every launch size"""
+    if request.param != "default":
+        monkeypatch.setenv("CRT_RENDER_KERNEL", request.param)
+    return request.param
+
 TOL = 1e-4   # north_star: "output matches the CPU reference at a fixed RNG seed within 1e-4 per channel"
 
 

@@ -1,0 +1,87 @@
+"""render_pool_kernel (stream pool: more RNG streams than lanes per wavefront) against the oracle and against render_tiles_kernel, at
+launch sizes where the back end selects it by itself (> 64 frames per launch): partial groups of streams, passes > 1, two-level
+scenes, materials, statistics builds, tile ownership."""
+import numpy as np
+import pytest
+
+from conftest import ASSETS, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("xml,kind,W,H,frames,passes", [("bunny_scene.xml", 0, 64, 48, 130, 1), ("tlas_scene.xml", 1, 64, 48, 200, 2),
+                                                         ("tower_scene.xml", 0, 48, 32, 97, 3), ("cube_scene.xml", 0, 32, 32, 300, 1)])
+def test_pool_kernel_matches_oracle(crt, orc, xml, kind, W, H, frames, passes):
+    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    ctx = crt.Context(W, H, collect_stats=True, max_frames_per_launch=4096)      # statistics build of the pool kernel: all counters
+    hs.upload(ctx)
+    ctx.render(1, frames, passes)
+    acc = ctx.accumulator()
+    assert ctx.timing()["render_launches"] == 1
+    o, _ = orc.load_scene(scene_path(xml), kind, ASSETS)
+    o.renderer_init(W, H)
+    o.set_params(5, passes)
+    o.render(frames, 4)
+    assert np.array_equal(acc, o.accumulator())
+    assert ctx.counters() == o.counters()
+    px, energy = ctx.resolve_screen(1.0 / (1 + frames * passes))
+    assert np.array_equal(px, o.screen()) and np.float32(energy) == np.float32(o.energy())
+
+
+@pytest.mark.parametrize("xml,kind,W,H,frames", [("bunny_scene.xml", 0, 320, 192, 256), ("tlas_scene.xml", 1, 256, 160, 192)])
+def test_pool_and_tiles_kernels_are_bit_identical(crt, monkeypatch, xml, kind, W, H, frames):
+    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    out = {}
+    for k in ("tiles", "pool"):
+        monkeypatch.setenv("CRT_RENDER_KERNEL", k)
+        ctx = crt.Context(W, H)
+        hs.upload(ctx)
+        ctx.render(1, frames, 1)
+        out[k] = (ctx.accumulator(), ctx.counters()["rays"])
+        ctx.close()
+    assert np.array_equal(out["pool"][0], out["tiles"][0]) and out["pool"][1] == out["tiles"][1]
+
+
+def test_pool_kernel_tile_ownership_and_frame_batches(crt, orc):
+    """two interleaved tile owners, launches of 96 frames (a partial group of streams each), summed == one context == oracle"""
+    W, H, frames = 96, 64, 200
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    tiles = (W // 16) * (H // 16)
+    total = np.zeros((H, W, 4), np.float32)
+    for r in range(2):
+        first, stride, count = crt.tile_partition(r, 2, tiles)
+        ctx = crt.Context(W, H, tile_first=first, tile_stride=stride, tile_count=count, max_frames_per_launch=96)
+        hs.upload(ctx)
+        ctx.render(1, frames, 1)
+        total += ctx.accumulator()
+        ctx.close()
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o.renderer_init(W, H)
+    o.render(frames, 4)
+    assert np.array_equal(total, o.accumulator())
+
+
+def test_scene_too_large_for_16_bit_references_falls_back(crt, monkeypatch):
+    """render_pool_kernel walks 16-bit node references; a scene that does not fit (here: forced) renders with render_tiles_kernel, same bits"""
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(64, 48); hs.upload(ctx); ctx.render(1, 100, 1); a = ctx.accumulator(); ctx.close()
+    monkeypatch.setenv("CRT_DEBUG_NO_REF16", "1")
+    ctx = crt.Context(64, 48); hs.upload(ctx); ctx.render(1, 100, 1); b = ctx.accumulator(); ctx.close()
+    assert np.array_equal(a, b)
+
+
+def test_timing_events_stay_bounded_in_a_tick_loop(crt):
+    """a host that renders frame after frame and never asks for the timing must not accumulate HIP events (completed launches are folded)"""
+    import ctypes as C
+    hs = crt.HostScene(scene_path("cube_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(32, 32)
+    hs.upload(ctx)
+    for i in range(600):
+        ctx.render(1 + i, 1, 1)
+        if i % 100 == 99:
+            ctx.sync()
+    ctx.sync()
+    ctx.L.crt_debug_live_events.restype = C.c_int
+    assert ctx.L.crt_debug_live_events(ctx.h) <= 4 * (64 + 600 // 6)          # bounded, far below the 2400 events of 600 launches
+    t = ctx.timing()
+    assert t["render_launches"] == 600 and t["render_kernel_ms"] > 0
