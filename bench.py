@@ -10,13 +10,17 @@ textures) already resident in HBM.  Rays = FindNearest calls (primary + secondar
 
 Steps are the consecutive 64-frame windows of ONE progressive render (spp 1..64, 65..128, ...): they are independent
 ((tile, frame) streams, renderer.cpp:120) except for the accumulation order, so the K steps are submitted as one
-crt_render of 64*K frames: the back end covers up to 64 windows with ONE render_tiles_kernel grid (a wavefront per
-(tile, window), expensive tiles first) and adds the samples to the accumulator in frame order behind it.
-Multi-GPU (weak scaling): every rank renders its own K consecutive windows of the full image (rank r: windows r*K ..),
-and ONE RCCL all-reduce of the float4 accumulators over xGMI closes the job (image = 64*K*N spp).
+crt_render of 64*K frames: the back end covers up to 64 windows with ONE render_pool_kernel grid (a wavefront per
+(tile, 128 consecutive frames), expensive tiles first) and adds the samples to the accumulator in frame order behind it.
+`value` is therefore PIPELINED throughput; the line also carries `single_render` = ONE 1280x720 / 64-spp render on its own
+(submit, wait), which ends on its most expensive tile and is several times slower per step.
+Multi-GPU (default `--split tiles`, BASELINE config 5 / SURVEY 8(e)): the 16x16 tiles of the ONE image are dealt round-robin
+over the ranks (tile ownership: every pixel is non-zero on exactly one rank) and ONE RCCL reduce of the float4 accumulator
+over xGMI closes the job: the image is bit-identical to the single-GPU one (strong scaling: the K windows are shared out).
+`--split frames` (weak scaling): every rank renders its own K windows of the full image, image = 64*K*N spp.
 `value` = rays of all ranks / max-over-ranks time.
 
-Rank 0 prints ONE JSON line with the contract fields + "roofline" (dominant kernel = render_tiles_kernel, HIP events
+Rank 0 prints ONE JSON line with the contract fields + "roofline" (dominant kernel = the render kernel, HIP events
 on the launch stream) + "cpu_baseline" (the CPU oracle on this box's host cores, bounded sample, rank 0, N = 1 only).
 """
 import argparse
@@ -85,6 +89,7 @@ def cpu_baseline(scene_xml, kind, W, H, budget_s=float(os.environ.get("CRT_BENCH
     o.render(2, 1)
     one_thread = o.counters()["rays"] / (time.perf_counter() - t2) / 1e6
     return {"value": round(c["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port", "value_1_thread": round(one_thread, 3),
+            "scaling_efficiency": round(c["rays"] / dt / 1e6 / max(one_thread * threads, 1e-9), 3),
             "sample": "%d frames (spp 2..%d) of the same %dx%d scene, %d threads (= usable host cores: affinity capped by the cgroup CPU quota), %.1f s" % (frames + 1, frames + 2, W, H, threads, dt),
             "ms_per_frame": round(dt / (frames + 1) * 1e3, 2)}
 
@@ -101,10 +106,12 @@ def main():
     ap.add_argument("--kind", type=int, default=0, help="0 = FileScene (single BVH), 1 = TLASFileScene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=7, help="HIP streams the render launches rotate over (crt_config.renderStreams)")
-    ap.add_argument("--split", choices=["frames", "tiles"], default="frames",
-                    help="N > 1: 'frames' (default, weak scaling) = every rank renders its own K windows of the full image; 'tiles' (strong scaling, BASELINE "
-                         "config 5) = the K windows of ONE image with the 16x16 tiles dealt round-robin over the ranks; both end in one RCCL all-reduce")
-    ap.add_argument("--latency-probe", action="store_true", help="also time three single 64-frame steps on their own (submit, wait) after the job")
+    ap.add_argument("--split", choices=["frames", "tiles"], default="tiles",
+                    help="N > 1: 'tiles' (default, strong scaling, north_star / BASELINE config 5) = the K windows of ONE image with the 16x16 tiles dealt "
+                         "round-robin over the ranks, exact image; 'frames' (weak scaling) = every rank renders its own K windows of the full image")
+    ap.add_argument("--reduce", choices=["reduce", "all_reduce"], default="reduce",
+                    help="N > 1: the collective that closes the job: ncclReduce of the float4 accumulator to rank 0 (default; SURVEY 8(e)) or ncclAllReduce")
+    ap.add_argument("--no-single-render", action="store_true", help="skip the single-render latency measurement (three 64-frame renders on their own after the job)")
     args = ap.parse_args()
 
     import torch
@@ -161,7 +168,10 @@ def main():
         ctx.render(window(0, n_steps), SPP * n_steps, 1)
         ctx.sync()
         if dist is not None:
-            crt.allreduce_accumulator(acc, dist)
+            if args.reduce == "reduce":
+                crt.reduce_accumulator(acc, dist, 0)
+            else:
+                crt.allreduce_accumulator(acc, dist)
             torch.cuda.synchronize()
 
     ctx.reserve(SPP * max(args.steps, args.warmup), 1)             # sample-slab pool for the whole job, allocated outside the timed region
@@ -180,12 +190,13 @@ def main():
     tm = ctx.timing()
     kernel_ms, acc_ms, launches = tm["render_kernel_ms"], tm["resolve_kernel_ms"], tm["render_launches"]
     rays = ctx.counters()["rays"]
-    # optional: latency of ONE step on its own (submit, wait), next to the job throughput
+    # latency of ONE step on its own (submit, wait), next to the job throughput: the literal "one WxH / SPP-spp render"
     lat = []
-    if args.latency_probe:
+    if not args.no_single_render:
         for i in range(3):
+            ctx.clear(); ctx.sync()
             t1 = time.perf_counter()
-            ctx.render(window(i, args.steps), SPP, 1)
+            ctx.render(1, SPP, 1)
             ctx.sync()
             lat.append((time.perf_counter() - t1) * 1e3)
         ctx.timing()
@@ -213,19 +224,24 @@ def main():
     alg_bytes_launch = algorithmic_bytes(counts) * (args.steps + args.warmup) / max(all_launches, 1)
     achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     job_launch_ms = kernel_ms / max(launches, 1)
-    valu_instrs = None
-    traffic = None          # HBM bytes of the job's launch from the PMC passes (tools/collect_profiles.sh), only for the workload they were collected on
+    # HBM bytes and VALU wave-instructions of the render kernel from the PMC passes (tools/collect_profiles.sh -> profiles/hbm_traffic.json),
+    # stored PER 64-FRAME WINDOW of the job's launch and scaled to this run's launch; only for the workload they were collected on
+    traffic = valu_instrs = pmc = None
+    windows_per_launch = (1 / launches_per_step) if launches_per_step else 0
     pmc_path = os.path.join(REPO, "profiles", "hbm_traffic.json")
     if os.path.exists(pmc_path):
         try:
             t = json.load(open(pmc_path))
-            if t.get("workload") == [args.scene, args.kind, W, H, SPP, args.steps]:
-                traffic = t.get("render_tiles_kernel_bytes_per_launch")
-                valu_instrs = t.get("render_tiles_kernel_valu_wave_instructions_per_launch")
+            if t.get("workload") == [args.scene, args.kind, W, H, SPP] and world == 1:
+                pmc = t
+                pw = t["per_window"]
+                traffic = int((pw["fetch_bytes_raw"] + pw["write_bytes"]) * windows_per_launch)
+                valu_instrs = int(pw["valu_wave_instructions"] * windows_per_launch)
         except Exception:
-            traffic = None
+            traffic = valu_instrs = pmc = None
+    single_ms = sorted(lat)[1] if lat else None
     out = {
-        "metric": "Mrays/sec (primary+secondary), 1280x720 64spp path trace",
+        "metric": "Mrays/sec (primary+secondary), %dx%d %dspp path trace — pipelined throughput over %d consecutive %d-spp windows of one progressive render (single_render = one such render alone)" % (W, H, SPP, args.steps, SPP),
         "value": round(rays / elapsed / 1e6, 2),
         "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -234,17 +250,22 @@ def main():
         "higher_is_better": True, "scaling": "weak" if args.split == "frames" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %s BVH-SAH path tracer, %dx%d, %d spp/step (passes=1, depthLimit=5); 1 step = %d frames = the next spp window of a "
-                               "progressive render; the %d steps are one crt_render job (%d render_tiles_kernel launch(es), a wavefront per (tile, window), "
+                               "progressive render; the %d steps are one crt_render job (%d render kernel launch(es), a wavefront per (tile, 128 consecutive frames), "
                                "+ ordered accumulate), one sync at the end%s"
                                % (args.scene, "TLASFileScene" if args.kind else "FileScene", W, H, SPP, SPP, args.steps, launches,
                                   "" if world == 1 else ("; every one of the %d ranks renders its own %d windows, ONE RCCL all-reduce of the float4 accumulator closes the job" % (world, args.steps)
-                                                         if args.split == "frames" else "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE RCCL all-reduce of the float4 accumulator closes the job" % world)),
-                   "latency_ms_single_step": round(sorted(lat)[1], 3) if lat else None,
+                                                         if args.split == "frames" else "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE RCCL %s of the float4 accumulator closes the job" % (world, args.reduce))),
+                   "latency_ms_single_step": round(single_ms, 3) if single_ms else None,
+                   "collective": None if world == 1 else args.reduce, "rccl_ranks": None if dist is None else dist.get_world_size(), "backend": None if dist is None else dist.get_backend(),
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
                    "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},
+        "single_render": None if not single_ms else {"ms": round(single_ms, 3), "mrays_s": round(counts["rays"] / single_ms / 1e3, 1),
+                                                     "what": "ONE %dx%d / %d-spp render on an idle GPU: clear, crt_render(1, %d, 1), sync (median of 3); it ends on its most expensive tile" % (W, H, SPP, SPP)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": "render_tiles_kernel", "avg_launch_ms": round(avg_launch_ms, 4), "launches": all_launches,
+                     "hbm_actual_frac": None if not traffic or job_launch_ms <= 0 else round(traffic / (job_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     "limiter": "valu_issue (fp32 instruction issue on divergent code; the algorithmic bytes are served by L2: see hbm_actual_frac and valu_issue)",
+                     "kernel": "render_pool_kernel" if launches_per_step and windows_per_launch > 1 else "render_tiles_kernel", "avg_launch_ms": round(avg_launch_ms, 4), "launches": all_launches,
                      "algorithmic_bytes_per_launch": int(alg_bytes_launch),
                      "job_launch_ms": round(job_launch_ms, 4), "job_launch_windows": round(1 / launches_per_step, 2) if launches_per_step else None,
                      "job_launch_achieved": round(algorithmic_bytes(counts) / max(launches_per_step, 1e-9) / (job_launch_ms * 1e-3) / 1e9, 2) if job_launch_ms > 0 else None,
@@ -253,9 +274,10 @@ def main():
                      "valu_issue": None if not valu_instrs or job_launch_ms <= 0 else {
                          "wave_instructions_per_job_launch": valu_instrs, "achieved_ginstr_s": round(valu_instrs / (job_launch_ms * 1e-3) / 1e9, 1),
                          "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "frac": round(valu_instrs / (job_launch_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GINSTR, 4),
-                         "note": "the limiter in practice: SQ_INSTS_VALU of the job's launch (PMC pass) / its duration, against the chip's measured fp32 VALU issue peak"},
+                         "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
+                         "note": "the limiter in practice: SQ_INSTS_VALU of the job's launch (PMC pass, per window x windows of this launch) / its duration, against the chip's measured fp32 VALU issue peak; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)"},
                      "counters_per_step": {k: round(v) for k, v in counts.items()},
-                     "note": "achieved = mean algorithmic bytes per render_tiles_kernel launch / mean launch duration over all its launches in this process (warm-up job + timed job; HIP events on the launch stream) = the average rocprofv3 --stats reports; job_launch_* = the timed job's launch alone; job_achieved = algorithmic GB/s over the whole timed region incl. the ordered accumulate; the bytes are algorithmic (SURVEY 8(d)) and mostly served by L2 — traffic = HBM bytes of the job's launch from the PMC passes"},
+                     "note": "achieved = mean algorithmic bytes per render_tiles_kernel launch / mean launch duration over all its launches in this process (warm-up job + timed job; HIP events on the launch stream) = the average rocprofv3 --stats reports; job_launch_* = the timed job's launch alone; job_achieved = algorithmic GB/s over the whole timed region incl. the ordered accumulate; the bytes are algorithmic (SURVEY 8(d)) and mostly served by L2 — traffic = HBM bytes of the job's launch from the PMC passes (per window x windows), hbm_actual_frac = traffic / job launch time / peak"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(xml, args.kind, W, H)

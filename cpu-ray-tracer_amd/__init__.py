@@ -401,6 +401,13 @@ def tile_partition(rank, world, n_tiles):
     return rank, world, count
 
 
+def reduce_accumulator(tensor, dist, dst=0):
+    """ncclReduce of the float4 accumulators to one rank: only rank `dst` ends up with the whole image.  With tile ownership
+    every pixel is non-zero on exactly one rank, so the sum is exact (x + 0 ...)."""
+    dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
+    return tensor
+
+
 def allreduce_accumulator(tensor, dist):
     """One collective per step: sum of the float4 accumulators over all ranks (RCCL over xGMI on GPUs, gloo in CPU tests)."""
     dist.all_reduce(tensor, op=dist.ReduceOp.SUM)

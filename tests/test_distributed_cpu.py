@@ -37,7 +37,10 @@ else:
         for i in range(count):
             o.set_spp(1 + f); o.set_tile_range(first + i * stride, 1); o.render(1, 1)
 acc = torch.from_numpy(o.accumulator())
-crt.allreduce_accumulator(acc, dist)
+if mode == "strong_reduce":
+    crt.reduce_accumulator(acc, dist, 0)          # bench.py's default collective: ncclReduce to rank 0
+else:
+    crt.allreduce_accumulator(acc, dist)
 if rank == 0:
     np.save(out, acc.numpy())
 dist.barrier()
@@ -83,9 +86,11 @@ def test_weak_scaling_two_ranks_gloo(orc, tmp_path):
     assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
 
 
-def test_tile_split_two_ranks_gloo(orc, tmp_path):
-    """tile ownership split: every pixel is non-zero on one rank only, so the reduced image is the single-rank image exactly"""
-    got = _run("strong", tmp_path, 29612)
+@pytest.mark.parametrize("mode,port", [("strong", 29612), ("strong_reduce", 29613)])
+def test_tile_split_two_ranks_gloo(orc, tmp_path, mode, port):
+    """tile ownership split: every pixel is non-zero on one rank only, so the reduced image (all_reduce, or reduce to rank 0 — bench.py's
+    default) is the single-rank image exactly"""
+    got = _run(mode, tmp_path, port)
     o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
     o.renderer_init(96, 64)
     o.render(3, 2)
