@@ -34,6 +34,28 @@ class Config(C.Structure):
                 ("maxFramesPerLaunch", C.c_int32), ("collectStats", C.c_int32), ("renderStreams", C.c_int32)]
 
 
+# ---- reference record layouts of include/crt_abi.h (ctypes mirrors; used by Context.upload_desc = INTEGRATION.md path A from Python) ----
+class BvhS(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("nodesUsed", C.c_uint32), ("triangles", C.c_void_p), ("triCount", C.c_uint32), ("triangleIndices", C.c_void_p),
+                ("objIdx", C.c_int32), ("matIdx", C.c_int32), ("T", C.c_float * 16), ("invT", C.c_float * 16)]
+
+
+class TextureS(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class MaterialS(C.Structure):
+    _fields_ = [("reflectivity", C.c_float), ("refractivity", C.c_float), ("absorption", C.c_float * 3), ("texture", C.c_int32)]
+
+
+class SceneDescS(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("bvhs", C.POINTER(BvhS)), ("bvhCount", C.c_uint32), ("tlasNodes", C.c_void_p), ("tlasNodeCount", C.c_uint32),
+                ("objMatIdx", C.c_void_p), ("objCount", C.c_uint32), ("materials", C.POINTER(MaterialS)), ("materialCount", C.c_uint32),
+                ("textures", C.POINTER(TextureS)), ("textureCount", C.c_uint32), ("floorTexture", C.c_int32), ("skyTexture", C.c_int32),
+                ("lightT", C.c_float * 16), ("lightInvT", C.c_float * 16), ("lightSize", C.c_float),
+                ("floorN", C.c_float * 3), ("floorD", C.c_float), ("floorInvto", C.c_float)]
+
+
 class CountersS(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "primary", "interior_iters", "leaf_iters", "tri_tests", "tlas_iters", "blas_visits", "mesh_hits")]
 
@@ -54,7 +76,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("objIdx", "<i4"
 ABI_SYMBOLS = ["crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
                "crt_render", "crt_reserve", "crt_whitted_tick", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
                "crt_reset_counters", "crt_get_timing", "crt_get_tile_clocks", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
-HOST_SYMBOLS = ["crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
+HOST_SYMBOLS = ["crt_host_math_probe", "crt_host_vertex_dedup", "crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
                 "crt_host_scene_triangle_count", "crt_host_scene_bvh_count", "crt_host_scene_bvh_info", "crt_host_scene_bvh_copy",
                 "crt_host_scene_bvh_move_and_refit", "crt_host_scene_blas_transform", "crt_host_scene_tlas_copy", "crt_host_camera_state", "crt_host_renderer_create",
                 "crt_host_renderer_destroy", "crt_host_renderer_init", "crt_host_renderer_set_camera", "crt_host_renderer_set_passes",
@@ -187,6 +209,42 @@ class Context:
         e = C.c_float()
         self._ck(self.L.crt_resolve_screen(self.h, C.c_float(scale), _p(px), C.byref(e)))
         return px, e.value
+
+    def upload_desc(self, kind, bvhs, textures, floor_texture, sky_texture, materials, light_T, light_invT, light_size=0.5,
+                    floor_n=(0, 1, 0), floor_d=1.0, floor_invto=None, obj_mat_idx=None, tlas_nodes=None):
+        """crt_upload_scene with arrays BUILT ELSEWHERE, in the reference's own layouts (INTEGRATION.md path A): bvhs = dicts with `nodes` (32-byte BVHNode
+        records), `tris` (112-byte Tri records), `triIndices` (uint32) and, for two-level scenes, objIdx / matIdx / T / invT; textures = uint32 (h, w)
+        arrays of 0x00RRGGBB texels; materials = (reflectivity, refractivity, absorption[3], texture index or -1).  Nothing of the repo's host front is involved."""
+        keep = []
+        bs = (BvhS * len(bvhs))()
+        for i, b in enumerate(bvhs):
+            nodes = np.ascontiguousarray(b["nodes"]); tris = np.ascontiguousarray(b["tris"]); idx = np.ascontiguousarray(b["triIndices"], np.uint32)
+            assert nodes.dtype.itemsize == 32 and tris.dtype.itemsize == 112
+            keep += [nodes, tris, idx]
+            bs[i].nodes = nodes.ctypes.data; bs[i].nodesUsed = int(b.get("nodesUsed", len(nodes))); bs[i].triangles = tris.ctypes.data; bs[i].triCount = len(tris)
+            bs[i].triangleIndices = idx.ctypes.data; bs[i].objIdx = int(b.get("objIdx", -1)); bs[i].matIdx = int(b.get("matIdx", -1))
+            bs[i].T[:] = list(np.asarray(b.get("T", np.eye(4)), np.float32).reshape(16)); bs[i].invT[:] = list(np.asarray(b.get("invT", np.eye(4)), np.float32).reshape(16))
+        ts = (TextureS * len(textures))()
+        for i, t in enumerate(textures):
+            t = np.ascontiguousarray(t, np.uint32); keep.append(t)
+            ts[i].pixels = t.ctypes.data; ts[i].height, ts[i].width = t.shape
+        ms = (MaterialS * max(len(materials), 1))()
+        for i, (refl, refr, ab, tex) in enumerate(materials):
+            ms[i].reflectivity = refl; ms[i].refractivity = refr; ms[i].absorption[:] = list(ab); ms[i].texture = tex
+        d = SceneDescS()
+        d.kind = kind; d.bvhs = bs; d.bvhCount = len(bvhs)
+        if tlas_nodes is not None:
+            tn = np.ascontiguousarray(tlas_nodes); keep.append(tn); d.tlasNodes = tn.ctypes.data; d.tlasNodeCount = len(tn)
+        if obj_mat_idx is not None:
+            om = np.ascontiguousarray(obj_mat_idx, np.int32); keep.append(om); d.objMatIdx = om.ctypes.data; d.objCount = len(om)
+        d.materials = ms; d.materialCount = len(materials); d.textures = ts; d.textureCount = len(textures)
+        d.floorTexture = floor_texture; d.skyTexture = sky_texture
+        d.lightT[:] = list(np.asarray(light_T, np.float32).reshape(16)); d.lightInvT[:] = list(np.asarray(light_invT, np.float32).reshape(16)); d.lightSize = light_size
+        d.floorN[:] = list(floor_n); d.floorD = floor_d
+        if floor_invto is None:                                              # file_scene.cpp:16: Plane(.., texW / 100) with an integer division
+            floor_invto = 1.0 / float(max(int(textures[floor_texture].shape[1]) // 100, 1)) if 0 <= floor_texture < len(textures) else 1.0
+        d.floorInvto = floor_invto
+        self._ck(self.L.crt_upload_scene(self.h, C.byref(d)))
 
     def find_nearest(self, O, D, inside=None):
         O = np.asarray(O, np.float32).reshape(-1, 3)
@@ -387,6 +445,23 @@ def load_image(path):
 # ------------------------------------------------------------------------------------------------------------
 # multi-GPU work split (one process per GPU, torch.distributed over RCCL) — pure arithmetic, shared by bench.py and tests
 # ------------------------------------------------------------------------------------------------------------
+def host_math_probe(inputs):
+    """test entry: the host front's tmplmath.h restatements (csrc/host/hmath.h), layout of the real-reference harness's ref_math_probe (tests/golden/make_golden.py)"""
+    inputs = np.ascontiguousarray(inputs, np.float32).reshape(-1, 12)
+    out = np.zeros((len(inputs), 120), np.float32)
+    lib().crt_host_math_probe(inputs.ctypes.data_as(C.c_void_p), C.c_uint32(len(inputs)), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def host_vertex_dedup(v8):
+    """test entry: the host front's unique-vertex table (csrc/host/accel.cpp Dedup): (corner indices, unique vertices)"""
+    v8 = np.ascontiguousarray(v8, np.float32).reshape(-1, 8)
+    idx = np.zeros(len(v8), np.uint32); uniq = np.zeros((len(v8), 8), np.float32)
+    L = lib(); L.crt_host_vertex_dedup.restype = C.c_uint32
+    n = L.crt_host_vertex_dedup(v8.ctypes.data_as(C.c_void_p), C.c_uint32(len(v8)), idx.ctypes.data_as(C.c_void_p), uniq.ctypes.data_as(C.c_void_p))
+    return idx, uniq[:n].copy()
+
+
 def spp_window(rank, frames_per_rank, first_spp=1):
     """Weak scaling: rank r renders frames whose spp counter runs first_spp + r*F .. first_spp + (r+1)*F - 1.
     (tile, frame) streams are independent (renderer.cpp:120), so windows can be rendered anywhere and summed."""

@@ -111,8 +111,13 @@ void Dedup(const MeshCorners& m, std::vector<float>& P, std::vector<float>& N, s
     table.reserve(n);
     for (size_t c = 0; c < n; c++) {
         const float v[8] = {m.pos[3 * c], m.pos[3 * c + 1], m.pos[3 * c + 2], m.nrm[3 * c], m.nrm[3 * c + 1], m.nrm[3 * c + 2], m.uv[2 * c], m.uv[2 * c + 1]};
-        Key k;
-        for (int i = 0; i < 8; i++) { uint32_t b; memcpy(&b, &v[i], 4); k.w[i] = (b == 0x80000000u) ? 0u : b; }
+        Key k; bool nan = false;
+        for (int i = 0; i < 8; i++) { uint32_t b; memcpy(&b, &v[i], 4); k.w[i] = (b == 0x80000000u) ? 0u : b; nan = nan || v[i] != v[i]; }
+        if (nan) {      // a NaN vertex equals nothing: model.cpp:46-48 appends it, and model.cpp:50's second lookup misses again and yields a value-initialised 0
+            P.insert(P.end(), v, v + 3); N.insert(N.end(), v + 3, v + 6); U.insert(U.end(), v + 6, v + 8);
+            indices.push_back(0u);
+            continue;
+        }
         auto it = table.find(k);
         if (it == table.end()) {
             const uint32_t id = (uint32_t)(P.size() / 3);
@@ -124,6 +129,8 @@ void Dedup(const MeshCorners& m, std::vector<float>& P, std::vector<float>& N, s
 }
 
 } // namespace
+
+void DedupVertices(const MeshCorners& m, std::vector<float>& P, std::vector<float>& N, std::vector<float>& U, std::vector<uint32_t>& indices) { Dedup(m, P, N, U, indices); }
 
 void RefitSAH(const std::vector<Tri>& tris, std::vector<BVHNode>& nodes, const std::vector<uint32_t>& idx, uint32_t nodesUsed)
 {

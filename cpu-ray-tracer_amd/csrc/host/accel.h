@@ -21,6 +21,8 @@ struct MeshCorners {           // tinyobj-resolved corners, three per triangle (
     size_t count() const { return pos.size() / 3; }
 };
 
+// unique-vertex table of Model / BLASBVH (model.cpp:16-54): index of every corner + the unique vertices, first occurrence wins (test entry)
+void DedupVertices(const MeshCorners& m, std::vector<float>& P, std::vector<float>& N, std::vector<float>& U, std::vector<uint32_t>& indices);
 // binned-SAH builder shared by BVH and BLASBVH (the reference duplicates the code: bvh.cpp:4-178, blas_bvh.cpp:82-256)
 void BuildSAH(std::vector<Tri>& triangles, std::vector<BVHNode>& nodes, std::vector<uint32_t>& triangleIndices, uint32_t& nodesUsed, uint32_t& maxDepth);
 // BVH::Refit / BLASBVH::Refit (bvh.cpp:26-43, blas_bvh.cpp:104-121): bounds of every node recomputed bottom-up for moved vertices,

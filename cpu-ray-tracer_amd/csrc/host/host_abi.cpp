@@ -174,4 +174,35 @@ int crt_host_image_load(const char* path, int* w, int* h, uint32_t** pixels)
 }
 void crt_host_free(void* p) { free(p); }
 
+// test entries: the host front's restatements of the tmplmath.h inlines / the Vertex table, same layout as the real-reference harness's probes (tests/golden/make_golden.py)
+void crt_host_math_probe(const float* in, uint32_t n, float* out)
+{
+    using namespace crt;
+    for (uint32_t i = 0; i < n; i++, in += 12, out += 120) {
+        const float3 a(in[0], in[1], in[2]), b(in[3], in[4], in[5]), ang(in[6], in[7], in[8]), sc(in[9], in[10], in[11]);
+        float* o = out;
+        const float3 na = normalize(a), rf = a - 2.0f * b * dot(b, a) /* reflect, tmplmath.h:506 */, cr = cross(a, b);
+        o[0] = na.x; o[1] = na.y; o[2] = na.z; o[3] = rf.x; o[4] = rf.y; o[5] = rf.z; o[6] = cr.x; o[7] = cr.y; o[8] = cr.z; o[9] = dot(a, b); o += 10;
+        const mat4 mt = mat4::Translate(a), rx = mat4::RotateX(ang.x), ry = mat4::RotateY(ang.y), rz = mat4::RotateZ(ang.z), ms = mat4::Scale(sc);
+        memcpy(o, mt.cell, 64); memcpy(o + 16, rx.cell, 64); memcpy(o + 32, ry.cell, 64); memcpy(o + 48, rz.cell, 64); memcpy(o + 64, ms.cell, 64); o += 80;
+        mat4 m = ry; m.cell[3] = a.x; m.cell[7] = a.y; m.cell[11] = a.z;
+        const mat4 inv = m.FastInvertedTransformNoScale();
+        memcpy(o, inv.cell, 64); o += 16;
+        aabb bb; bb.Grow(a); bb.Grow(b); bb.Grow(sc);
+        o[0] = bb.bmin3.x; o[1] = bb.bmin3.y; o[2] = bb.bmin3.z; o[3] = bb.bmax3.x; o[4] = bb.bmax3.y; o[5] = bb.bmax3.z; o[6] = bb.Area(); o += 7;
+        aabb b1, b2; b1.Grow(a); b1.Grow(b); b2.Grow(ang); b2.Grow(sc); b1.Grow(b2);
+        o[0] = b1.bmin3.x; o[1] = b1.bmin3.y; o[2] = b1.bmin3.z; o[3] = b1.bmax3.x; o[4] = b1.bmax3.y; o[5] = b1.bmax3.z; o[6] = b1.Area();
+    }
+}
+uint32_t crt_host_vertex_dedup(const float* v8, uint32_t n, uint32_t* idx, float* unique8)
+{
+    crt::MeshCorners m;
+    for (uint32_t i = 0; i < n; i++) { m.pos.insert(m.pos.end(), v8 + 8 * i, v8 + 8 * i + 3); m.nrm.insert(m.nrm.end(), v8 + 8 * i + 3, v8 + 8 * i + 6); m.uv.insert(m.uv.end(), v8 + 8 * i + 6, v8 + 8 * i + 8); }
+    std::vector<float> P, N, U; std::vector<uint32_t> ix;
+    crt::DedupVertices(m, P, N, U, ix);
+    memcpy(idx, ix.data(), ix.size() * 4);
+    for (size_t k = 0; k < P.size() / 3; k++) { memcpy(unique8 + 8 * k, &P[3 * k], 12); memcpy(unique8 + 8 * k + 3, &N[3 * k], 12); memcpy(unique8 + 8 * k + 6, &U[2 * k], 8); }
+    return (uint32_t)(P.size() / 3);
+}
+
 } // extern "C"

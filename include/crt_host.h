@@ -68,6 +68,11 @@ crt_ctx* crt_host_renderer_ctx(crt_host_renderer* r);
 int  crt_host_obj_load(const char* path, uint32_t* corners, float** pos, float** nrm, float** uv);   /* arrays owned by the library until crt_host_free */
 int  crt_host_image_load(const char* path, int* width, int* height, uint32_t** pixels);
 void crt_host_free(void* p);
+/* test entries (parity of the host front's math with the reference's inline template/tmplmath.h functions and infra/helper.h's Vertex table):
+ * in = n x 12 floats (a, b, angles, scale), out = n x 120 floats — normalize :480, reflect :506, cross :512, dot :458, mat4::Translate :735,
+ * RotateX/Y/Z :673-675, Scale :677, FastInvertedTransformNoScale :745-768, aabb::Grow/Area :580-598; layout in tests/golden/make_golden.py */
+void crt_host_math_probe(const float* in, uint32_t n, float* out);
+uint32_t crt_host_vertex_dedup(const float* v8, uint32_t n, uint32_t* idx, float* unique8);   /* model.cpp:16-54 on n corners of 8 floats; returns the unique count */
 
 #ifdef __cplusplus
 }

@@ -810,8 +810,15 @@ static void dedup(const ObjDesc& o, std::vector<float>& P, std::vector<float>& N
         float v[8] = {o.pos[3 * c], o.pos[3 * c + 1], o.pos[3 * c + 2],
                       o.nrm.empty() ? 0.0f : o.nrm[3 * c], o.nrm.empty() ? 0.0f : o.nrm[3 * c + 1], o.nrm.empty() ? 0.0f : o.nrm[3 * c + 2],
                       o.uv.empty() ? 0.0f : o.uv[2 * c], o.uv.empty() ? 0.0f : o.uv[2 * c + 1]};
-        VKey k;
-        for (int i = 0; i < 8; i++) { uint32_t b = f2bits(v[i]); if (b == 0x80000000u) b = 0; k.b[i] = b; }
+        VKey k; bool nan = false;
+        for (int i = 0; i < 8; i++) { uint32_t b = f2bits(v[i]); if (b == 0x80000000u) b = 0; k.b[i] = b; nan = nan || v[i] != v[i]; }
+        if (nan) {
+            // a vertex with a NaN component equals nothing, not even itself: `uniqueVertices[vertex] = size` appends it, and the second
+            // `uniqueVertices[vertex]` of model.cpp:50 misses again and value-initialises a fresh entry: the corner gets index 0
+            P.insert(P.end(), v, v + 3); Nn.insert(Nn.end(), v + 3, v + 6); U.insert(U.end(), v + 6, v + 8);
+            idx.push_back(0u);
+            continue;
+        }
         auto it = seen.find(k);
         uint32_t id;
         if (it == seen.end()) {
@@ -1269,6 +1276,35 @@ int orc_png_unfilter(const uint8_t* raw, uint8_t* out, int stride, int h, int fb
         }
     }
     return 0;
+}
+
+// probes of the restated tmplmath.h / helper.h pieces, same layout as oracle/ref_build/ref_harness.cpp's ref_math_probe / ref_vertex_dedup
+void orc_math_probe(const float* in, uint32_t n, float* out)
+{
+    for (uint32_t i = 0; i < n; i++, in += 12, out += 120) {
+        const V3 a = v3(in[0], in[1], in[2]), b = v3(in[3], in[4], in[5]), ang = v3(in[6], in[7], in[8]), sc = v3(in[9], in[10], in[11]);
+        float* o = out;
+        st3(o, normalize(a)); st3(o + 3, reflect(a, b)); st3(o + 6, cross(a, b)); o[9] = dot(a, b); o += 10;
+        const M4 mt = m4_translate(a), rx = m4_rotx(ang.x), ry = m4_roty(ang.y), rz = m4_rotz(ang.z), ms = m4_scale(sc);
+        memcpy(o, mt.c, 64); memcpy(o + 16, rx.c, 64); memcpy(o + 32, ry.c, 64); memcpy(o + 48, rz.c, 64); memcpy(o + 64, ms.c, 64); o += 80;
+        M4 m = ry; m.c[3] = a.x; m.c[7] = a.y; m.c[11] = a.z;
+        const M4 inv = m4_fast_inverted_noscale(m);
+        memcpy(o, inv.c, 64); o += 16;
+        Box bb; bb.grow(a); bb.grow(b); bb.grow(sc);
+        st3(o, bb.lo); st3(o + 3, bb.hi); o[6] = bb.area(); o += 7;
+        Box b1, b2; b1.grow(a); b1.grow(b); b2.grow(ang); b2.grow(sc); b1.grow(b2);
+        st3(o, b1.lo); st3(o + 3, b1.hi); o[6] = b1.area();
+    }
+}
+uint32_t orc_vertex_dedup(const float* v8, uint32_t n, uint32_t* idx, float* unique8)
+{
+    ObjDesc o; o.nCorners = (int)n;
+    for (uint32_t i = 0; i < n; i++) { o.pos.insert(o.pos.end(), v8 + 8 * i, v8 + 8 * i + 3); o.nrm.insert(o.nrm.end(), v8 + 8 * i + 3, v8 + 8 * i + 6); o.uv.insert(o.uv.end(), v8 + 8 * i + 6, v8 + 8 * i + 8); }
+    std::vector<float> P, Nn, U; std::vector<uint32_t> ix;
+    dedup(o, P, Nn, U, ix);
+    memcpy(idx, ix.data(), ix.size() * 4);
+    for (size_t k = 0; k < P.size() / 3; k++) { memcpy(unique8 + 8 * k, &P[3 * k], 12); memcpy(unique8 + 8 * k + 3, &Nn[3 * k], 12); memcpy(unique8 + 8 * k + 6, &U[2 * k], 8); }
+    return (uint32_t)(P.size() / 3);
 }
 
 float orc_expf(float x) { return det_expf(x); }

@@ -106,6 +106,8 @@ int orc_whitted_render(orc_ctx*, int n_threads);               /* one frame into
 int orc_png_unfilter(const uint8_t* raw, uint8_t* out, int stride, int h, int fb);
 
 /* deterministic math used for absorption / skydome lookups (see DESIGN.md "numerics") */
+void orc_math_probe(const float* in12, uint32_t n, float* out120);
+uint32_t orc_vertex_dedup(const float* v8, uint32_t n, uint32_t* idx, float* unique8);
 float orc_expf(float x);
 float orc_atan2f(float y, float x);
 float orc_acosf(float x);

@@ -560,6 +560,26 @@ def load_scene(xml_path, kind, base_dir=None):
     return o, sc
 
 
+def _math_probe(fn, inputs):
+    inputs = np.ascontiguousarray(inputs, np.float32).reshape(-1, 12)
+    out = np.zeros((len(inputs), 120), np.float32)
+    fn(_fp(inputs), C.c_uint32(len(inputs)), _fp(out))
+    return out
+
+
+def math_probe(inputs):
+    """the oracle's restatement of the same functions, same layout as Ref.math_probe"""
+    return _math_probe(lib().orc_math_probe, inputs)
+
+
+def vertex_dedup(v8):
+    v8 = np.ascontiguousarray(v8, np.float32).reshape(-1, 8)
+    idx = np.zeros(len(v8), np.uint32); uniq = np.zeros((len(v8), 8), np.float32)
+    L = lib(); L.orc_vertex_dedup.restype = C.c_uint32
+    n = L.orc_vertex_dedup(_fp(v8), C.c_uint32(len(v8)), _fp(idx), _fp(uniq))
+    return idx, uniq[:n].copy()
+
+
 class Ref:
     """oracle/_ref: the reference's own bvh.cpp / tinyobj / stb_image compiled in place (authoring container only)."""
 
@@ -604,6 +624,18 @@ class Ref:
 
     def bvh_free(self, h):
         self.L.ref_bvh_free(h)
+
+    def math_probe(self, inputs):
+        """the reference's inline tmplmath.h functions (normalize, reflect, cross, dot, mat4 factories, FastInvertedTransformNoScale, aabb): (n, 12) -> (n, 120)"""
+        return _math_probe(self.L.ref_math_probe, inputs)
+
+    def vertex_dedup(self, v8):
+        """real Vertex::operator== / std::hash<Vertex> in a real std::unordered_map (infra/helper.h:28-86, model.cpp:44-50): (idx, unique vertices, hashes)"""
+        v8 = np.ascontiguousarray(v8, np.float32).reshape(-1, 8)
+        idx = np.zeros(len(v8), np.uint32); uniq = np.zeros((len(v8), 8), np.float32); hsh = np.zeros(len(v8), np.uint64)
+        self.L.ref_vertex_dedup.restype = C.c_uint32
+        n = self.L.ref_vertex_dedup(_fp(v8), C.c_uint32(len(v8)), _fp(idx), _fp(uniq), _fp(hsh))
+        return idx, uniq[:n].copy(), hsh
 
     def obj_load(self, path):
         n = C.c_uint32()

@@ -8,6 +8,9 @@
  *   template/camera.h        -> Camera(): default frustum, GetPrimaryRay, SetCameraState (compiled for its fixed SCRWIDTH x SCRHEIGHT = 1024 x 640)
  *   template/texture.h       -> Texture::LoadFromFile (0x00RRGGBB packing), Texture::Sample
  *   template/material.h      -> Material::GetAlbedo
+ *   template/tmplmath.h      -> the inline functions on the path: normalize, reflect, cross, dot, mat4::Translate / RotateX / RotateY / RotateZ / Scale,
+ *                               mat4::FastInvertedTransformNoScale, aabb::Grow / Area   (ref_math_probe)
+ *   infra/helper.h           -> Vertex::operator== and std::hash<Vertex> inside a real std::unordered_map<Vertex, uint32_t>   (ref_vertex_dedup)
  * The three headers need three names that template/precomp.h / template/opengl.h declare and that live in translation units this
  * image cannot build (template.cpp, opencl.cpp: <windows.h>, OpenGL, OpenCL): IsKeyDown (precomp.h:143), WindowHasFocus (opengl.h:23)
  * and FatalError (precomp.h:203).  They are DECLARED below exactly as there and never defined: only Camera::HandleInput and the
@@ -148,6 +151,52 @@ void ref_texture_sample(const uint32_t* px, int w, int h, const float* uv, uint3
         const float3 a = m.GetAlbedo(float2(uv[2 * i], uv[2 * i + 1]));
         albedo[3 * i] = a.x; albedo[3 * i + 1] = a.y; albedo[3 * i + 2] = a.z;
     }
+}
+
+/* The inline functions of template/tmplmath.h that the path uses (file:line in the reference): normalize :480, reflect :506, cross :512, dot :458,
+ * mat4::Translate :735, RotateX/Y/Z :673-675, Scale :677, FastInvertedTransformNoScale :745-768 (the non-MSVC branch is what compiles here),
+ * aabb::Grow(float3) / Grow(aabb) / Area :580-598.  mat4 PRODUCTS (operator*, tmplmath.cpp:109-122) are not inline and cannot be built here.
+ * in: n x 12 floats (a[3], b[3], angles[3], s[3]); out: n x 120 floats, layout stated in tests/golden/make_golden.py. */
+void ref_math_probe(const float* in, uint32_t n, float* out)
+{
+    for (uint32_t i = 0; i < n; i++, in += 12, out += 120) {
+        const float3 a(in[0], in[1], in[2]), b(in[3], in[4], in[5]), ang(in[6], in[7], in[8]), sc(in[9], in[10], in[11]);
+        float* o = out;
+        const float3 na = normalize(a), rf = reflect(a, b), cr = cross(a, b);
+        o[0] = na.x; o[1] = na.y; o[2] = na.z; o[3] = rf.x; o[4] = rf.y; o[5] = rf.z; o[6] = cr.x; o[7] = cr.y; o[8] = cr.z; o[9] = dot(a, b); o += 10;
+        const mat4 mt = mat4::Translate(a), rx = mat4::RotateX(ang.x), ry = mat4::RotateY(ang.y), rz = mat4::RotateZ(ang.z), ms = mat4::Scale(sc);
+        memcpy(o, mt.cell, 64); memcpy(o + 16, rx.cell, 64); memcpy(o + 32, ry.cell, 64); memcpy(o + 48, rz.cell, 64); memcpy(o + 64, ms.cell, 64); o += 80;
+        mat4 m = ry;                                       /* a rigid transform assembled without operator*: rotation block of RotateY, translation a */
+        m.cell[3] = a.x; m.cell[7] = a.y; m.cell[11] = a.z;
+        const mat4 inv = m.FastInvertedTransformNoScale();
+        memcpy(o, inv.cell, 64); o += 16;
+        aabb bb; bb.Grow(a); bb.Grow(b); bb.Grow(sc);
+        o[0] = bb.bmin[0]; o[1] = bb.bmin[1]; o[2] = bb.bmin[2]; o[3] = bb.bmax[0]; o[4] = bb.bmax[1]; o[5] = bb.bmax[2]; o[6] = bb.Area(); o += 7;
+        aabb b1, b2; b1.Grow(a); b1.Grow(b); b2.Grow(ang); b2.Grow(sc); b1.Grow(b2);
+        o[0] = b1.bmin[0]; o[1] = b1.bmin[1]; o[2] = b1.bmin[2]; o[3] = b1.bmax[0]; o[4] = b1.bmax[1]; o[5] = b1.bmax[2]; o[6] = b1.Area();
+    }
+}
+/* The three statements of infra/model.cpp:44-50 / infra/blas_bvh.cpp:46-52 around the REAL Vertex (operator== = float equality, infra/helper.h:34-37)
+ * and the REAL std::hash<Vertex> (helper.h:40-86) in a real std::unordered_map: idx[i] = index of corner i, unique = the vertices array (8 floats each).
+ * Returns the number of unique vertices; hash[i] = std::hash<Vertex> of corner i. */
+uint32_t ref_vertex_dedup(const float* v8, uint32_t n, uint32_t* idx, float* unique8, uint64_t* hash)
+{
+    std::unordered_map<Vertex, uint32_t> uniqueVertices{};
+    std::vector<Vertex> vertices;
+    for (uint32_t i = 0; i < n; i++) {
+        Vertex vertex{};
+        vertex.position = {v8[8 * i], v8[8 * i + 1], v8[8 * i + 2]};
+        vertex.normal = {v8[8 * i + 3], v8[8 * i + 4], v8[8 * i + 5]};
+        vertex.uv = {v8[8 * i + 6], v8[8 * i + 7]};
+        if (uniqueVertices.count(vertex) == 0) { uniqueVertices[vertex] = static_cast<uint32_t>(vertices.size()); vertices.push_back(vertex); }
+        idx[i] = uniqueVertices[vertex];
+        hash[i] = (uint64_t)std::hash<Vertex>()(vertex);
+    }
+    for (size_t k = 0; k < vertices.size(); k++) {
+        const Vertex& v = vertices[k]; float* u = unique8 + 8 * k;
+        u[0] = v.position.x; u[1] = v.position.y; u[2] = v.position.z; u[3] = v.normal.x; u[4] = v.normal.y; u[5] = v.normal.z; u[6] = v.uv.x; u[7] = v.uv.y;
+    }
+    return (uint32_t)vertices.size();
 }
 
 } // extern "C"

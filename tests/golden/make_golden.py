@@ -80,6 +80,10 @@ def main():
             hits = ref.bvh_intersect(h, O, D)
             rays[m] = dict(O=O, D=D, t=hits["t"], u=hits["u"], v=hits["v"], objIdx=hits["objIdx"], triIdx=hits["triIdx"],
                            traversed=hits["traversed"], tested=hits["tested"])
+        if m == "bunny":
+            # --- ref_bunny_built: the arrays the REAL bvh.cpp built (nodes, triangleIndices) + its input triangles, in the reference's layouts:
+            # fed to crt_upload_scene directly by tests/test_gpu_upload_path_a.py (INTEGRATION.md path A, no host front of this repo involved)
+            np.savez_compressed(os.path.join(HERE, "ref_bunny_built.npz"), nodes=rb["nodes"], triIndices=rb["triIndices"], tris=tris)
         if m in ("bunny", "cube", "teapot"):
             # --- ref_refit: the reference's BVH::Refit (bvh.cpp:26-43) after a deterministic deformation of the vertices ---------
             moved = deform(np.stack([tris["vertex0"], tris["vertex1"], tris["vertex2"]], axis=1))
@@ -104,6 +108,25 @@ def main():
                               tga=crc(ref.texture_load(os.path.join(RA, "textures/Stylized_Wood_basecolor.tga"))),
                               jpg=crc(ref.texture_load(os.path.join(RA, "textures/Wood_Tower_Col.jpg"))))
     np.save(os.path.join(HERE, "ref_texture_uv.npy"), uv)
+    # --- ref_math: the reference's inline tmplmath.h functions on the path + infra/helper.h's Vertex table ------------------------------
+    # math_probe input row = a[3], b[3], angles[3] (radians), s[3]; output row (120 floats) = normalize(a)[3], reflect(a, b)[3], cross(a, b)[3], dot(a, b),
+    # mat4::Translate(a), RotateX(angles.x), RotateY(angles.y), RotateZ(angles.z), Scale(s) [16 each], FastInvertedTransformNoScale(RotateY(angles.y) with
+    # translation a)[16], aabb after Grow(a), Grow(b), Grow(s): bmin[3], bmax[3], Area(); aabb{a,b}.Grow(aabb{angles,s}): bmin[3], bmax[3], Area()
+    rng = np.random.default_rng(2024)
+    mi = rng.uniform(-4, 4, (400, 12)).astype(np.float32)
+    mi[:40, 6:9] = np.deg2rad(rng.integers(-36, 36, (40, 3)) * 10).astype(np.float32)        # the scene files' whole-degree rotations (x kDeg2Rad happens in the caller)
+    mi[40:50, 0:3] = 0; mi[50:60, 3:6] = mi[50:60, 0:3]; mi[60:64] = 0; mi[64:70, 9:12] = 1          # zero vector (normalize -> NaN), degenerate boxes, all zero, unit scale
+    mo = ref.math_probe(mi)
+    np.savez_compressed(os.path.join(HERE, "ref_math.npz"), inputs=mi, outputs=mo)
+    base = rng.uniform(-1, 1, (60, 8)).astype(np.float32)
+    v8 = np.concatenate([base, base[::3], base[5:25]])                                              # duplicates in a shuffled order
+    v8 = v8[rng.permutation(len(v8))]
+    z = v8[:12].copy(); z[:, 1] = 0.0; z2 = z.copy(); z2[:, 1] = -0.0                                 # +0 / -0 compare equal: first occurrence wins
+    nanv = v8[3:6].copy(); nanv[:, 4] = np.nan                                                        # a NaN component equals nothing (model.cpp:50 then yields index 0)
+    v8 = np.concatenate([v8, z, z2, z, nanv, v8[:7], nanv]).astype(np.float32)
+    vi, vu, vh = ref.vertex_dedup(v8)
+    np.savez_compressed(os.path.join(HERE, "ref_vertex.npz"), corners=v8, idx=vi, unique=vu, hash=vh)
+    out["ref_math"] = dict(rows=int(len(mi)), outputs=crc(mo), vertex_corners=int(len(v8)), vertex_unique=int(len(vu)), vertex_idx=crc(vi))
     # --- orc_render: oracle accumulators of the BASELINE scenes at small sizes (regression vectors) ------------------
     out["orc_render"] = {}
     for name, xml, kind, W, H, frames in [("bunny", "bunny_scene.xml", 0, 96, 64, 4), ("tlas", "tlas_scene.xml", 1, 96, 64, 3),

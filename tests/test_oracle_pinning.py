@@ -295,3 +295,61 @@ def test_deterministic_math_accuracy(orc):
 
 def test_reference_struct_sizes(orc):
     assert orc.TRI_DTYPE.itemsize == 112 and orc.NODE_DTYPE.itemsize == 32 and orc.TLAS_DTYPE.itemsize == 32
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# template/tmplmath.h inline functions on the path + infra/helper.h's Vertex table: pinned to the
+# real reference through oracle/_ref (ref_math_probe / ref_vertex_dedup) and its committed outputs tests/golden/ref_math.npz, ref_vertex.npz
+# ---------------------------------------------------------------------------------------------------------------
+MATH_FIELDS = [("normalize", 0, 3), ("reflect", 3, 6), ("cross", 6, 9), ("dot", 9, 10), ("mat4::Translate", 10, 26), ("mat4::RotateX", 26, 42),
+               ("mat4::RotateY", 42, 58), ("mat4::RotateZ", 58, 74), ("mat4::Scale", 74, 90), ("FastInvertedTransformNoScale", 90, 106),
+               ("aabb::Grow(float3) / Area", 106, 113), ("aabb::Grow(aabb) / Area", 113, 120)]
+
+
+def _same_bits(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.uint32); b = np.ascontiguousarray(b, np.float32).view(np.uint32)
+    nan = lambda x: (x & 0x7fffffff) > 0x7f800000                      # any NaN matches any NaN (payload / sign of an invalid operation are not specified)
+    return bool(np.all((a == b) | (nan(a) & nan(b))))
+
+
+@pytest.mark.parametrize("who", ["oracle", "host_front"])
+def test_tmplmath_inlines_match_reference_golden(orc, who):
+    z = np.load(os.path.join(GOLDEN, "ref_math.npz"))
+    assert crc(z["outputs"]) == G["ref_math"]["outputs"] and len(z["inputs"]) == G["ref_math"]["rows"]
+    if who == "oracle":
+        got = orc.math_probe(z["inputs"])
+    else:
+        from conftest import load_crt
+        got = load_crt().host_math_probe(z["inputs"])
+    for name, a, b in MATH_FIELDS:
+        assert _same_bits(got[:, a:b], z["outputs"][:, a:b]), name
+
+
+@pytest.mark.parametrize("who", ["oracle", "host_front"])
+def test_vertex_table_matches_reference_golden(orc, who):
+    """Vertex::operator== is float equality (+0 == -0: the first occurrence's bits are kept; a NaN vertex equals nothing and model.cpp:50's second
+    lookup then yields index 0): corner indices and the unique-vertex array of the real std::unordered_map<Vertex, uint32_t>"""
+    z = np.load(os.path.join(GOLDEN, "ref_vertex.npz"))
+    assert crc(z["idx"]) == G["ref_math"]["vertex_idx"] and len(z["unique"]) == G["ref_math"]["vertex_unique"]
+    if who == "oracle":
+        idx, uniq = orc.vertex_dedup(z["corners"])
+    else:
+        from conftest import load_crt
+        idx, uniq = load_crt().host_vertex_dedup(z["corners"])
+    assert np.array_equal(idx, z["idx"])
+    assert uniq.shape == z["unique"].shape and _same_bits(uniq, z["unique"])
+
+
+def test_tmplmath_and_vertex_live(orc):
+    """authoring container only: the same probes against oracle/_ref directly, on fresh random inputs"""
+    try:
+        ref = orc.Ref()
+    except FileNotFoundError:
+        pytest.skip("oracle/_ref is built only where /root/reference is mounted")
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-10, 10, (3000, 12)).astype(np.float32)
+    assert _same_bits(orc.math_probe(x), ref.math_probe(x))
+    v = np.round(rng.uniform(-1, 1, (4000, 8)) * 4).astype(np.float32) / 4          # many exact duplicates, +0 and -0
+    i1, u1 = orc.vertex_dedup(v)
+    i2, u2, _ = ref.vertex_dedup(v)
+    assert np.array_equal(i1, i2) and _same_bits(u1, u2)
