@@ -106,25 +106,43 @@ def test_config3_tlas_full_size_spot_tiles(crt, orc):
         assert np.array_equal(acc[y0:y0 + 16, x0:x0 + 16], o.accumulator()[y0:y0 + 16, x0:x0 + 16]), t
 
 
-def test_config5_4k_tile_split_property(crt):
-    """BASELINE config 5 shape (3840x2160, tiles split across ranks) on one GPU: two interleaved half-images at 4 spp sum to the whole"""
+def test_config5_4k_1024spp_eight_way_tile_split(crt, orc):
+    """BASELINE config 5 at its stated size on one GPU: TLAS scene, 3840x2160, 1024 spp.  The eight tile owners of an 8-GPU run
+    (crt.tile_partition(r, 8, tiles): rank r owns tiles r, r + 8, ...) are rendered one after another and summed — what the RCCL reduce of the
+    float4 accumulators does: every pixel is non-zero on exactly one rank — and must equal the whole-image context bit for bit;
+    three tiles (sky / floor, instanced meshes) are also checked against the oracle at all 1024 spp."""
     hs = crt.HostScene(scene_path("tlas_scene.xml"), 1, ASSETS)
-    Wk, Hk = 3840, 2160
+    Wk, Hk, S = 3840, 2160, 1024
     tiles = (Wk // 16) * (Hk // 16)
     whole = crt.Context(Wk, Hk)
     hs.upload(whole)
-    whole.render(1, 4, 1)
+    whole.render(1, S, 1)
     acc = whole.accumulator()
+    rays = whole.counters()["rays"]
     whole.close()
+    assert np.isfinite(acc).all() and not acc[..., 3].any()
     total = np.zeros_like(acc)
-    for r in range(2):
-        first, stride, count = crt.tile_partition(r, 2, tiles)
+    owned_rays = 0
+    for r in range(8):
+        first, stride, count = crt.tile_partition(r, 8, tiles)
         cx = crt.Context(Wk, Hk, tile_first=first, tile_stride=stride, tile_count=count)
         hs.upload(cx)
-        cx.render(1, 4, 1)
-        total += cx.accumulator()
+        cx.render(1, S, 1)
+        part = cx.accumulator()
+        owned_rays += cx.counters()["rays"]
         cx.close()
-    assert np.array_equal(total, acc)
+        assert not (total.astype(bool) & part.astype(bool)).any()            # ownership: no pixel is touched by two ranks
+        total += part
+    assert np.array_equal(total, acc) and owned_rays == rays
+    o, _ = orc.load_scene(scene_path("tlas_scene.xml"), 1, ASSETS)
+    o.renderer_init(Wk, Hk)
+    tw = Wk // 16
+    for t in [tw * 3 + 7, tw * 70 + 120, tw * 95 + 131]:
+        o.clear()
+        o.set_tile_range(t, 1)
+        o.render(S, 8)
+        x0, y0 = (t % tw) * 16, (t // tw) * 16
+        assert np.array_equal(acc[y0:y0 + 16, x0:x0 + 16], o.accumulator()[y0:y0 + 16, x0:x0 + 16]), t
 
 
 def test_config4_tower_1080p_256spp(crt, orc):
