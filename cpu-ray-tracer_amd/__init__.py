@@ -20,6 +20,7 @@ REPO = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("CRT_LIB_PATH") or os.path.join(HERE, "libcrt_amd.so")   # CRT_LIB_PATH: A/B builds of the same library (tools/ab_bench.py)
 
 SCENE_FILE, SCENE_TLAS = 0, 1
+UPDATE_TRANSFORMS, UPDATE_BOUNDS = 1, 2        # crt_update_scene flags
 
 
 class CrtError(RuntimeError):
@@ -73,10 +74,10 @@ RAY_DTYPE = np.dtype([("O", "<f4", 3), ("D", "<f4", 3), ("inside", "<i4")])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("objIdx", "<i4"), ("triIdx", "<i4"), ("traversed", "<i4"), ("tested", "<i4")])
 
 # every symbol include/crt_abi.h and include/crt_host.h declare (tests check the library exports all of them)
-ABI_SYMBOLS = ["crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
+ABI_SYMBOLS = ["crt_update_scene", "crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
                "crt_render", "crt_reserve", "crt_whitted_tick", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
                "crt_reset_counters", "crt_get_timing", "crt_get_tile_clocks", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
-HOST_SYMBOLS = ["crt_host_math_probe", "crt_host_vertex_dedup", "crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
+HOST_SYMBOLS = ["crt_host_scene_set_transform", "crt_host_scene_update", "crt_host_math_probe", "crt_host_vertex_dedup", "crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
                 "crt_host_scene_triangle_count", "crt_host_scene_bvh_count", "crt_host_scene_bvh_info", "crt_host_scene_bvh_copy",
                 "crt_host_scene_bvh_move_and_refit", "crt_host_scene_blas_transform", "crt_host_scene_tlas_copy", "crt_host_camera_state", "crt_host_renderer_create",
                 "crt_host_renderer_destroy", "crt_host_renderer_init", "crt_host_renderer_set_camera", "crt_host_renderer_set_passes",
@@ -333,6 +334,15 @@ class HostScene:
         """BVH::Refit for moved vertices: positions = (triCount, 3, 3) floats in the reference's triangle order; upload() again afterwards"""
         positions = np.ascontiguousarray(positions, np.float32)
         self._ck(self.L.crt_host_scene_bvh_move_and_refit(self.h, int(i), _p(positions), C.c_uint32(positions.shape[0])))
+
+    def set_transform(self, i, T):
+        """BLASBVH::SetTransform(T) of instance i (T = 4x4 row-major, rigid) + TLASBVH::Build on the host; update(ctx, UPDATE_TRANSFORMS) moves it to the device"""
+        T = np.ascontiguousarray(T, np.float32).reshape(16)
+        self._ck(self.L.crt_host_scene_set_transform(self.h, int(i), _p(T)))
+
+    def update(self, ctx, what):
+        """in-place device update (crt_update_scene): UPDATE_TRANSFORMS after set_transform, UPDATE_BOUNDS after move_and_refit; no re-upload"""
+        self._ck(self.L.crt_host_scene_update(self.h, ctx.h, C.c_uint32(what)))
 
     def blas_transform(self, i):
         T, invT, lo, hi = np.zeros(16, np.float32), np.zeros(16, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)

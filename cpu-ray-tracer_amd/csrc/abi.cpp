@@ -65,6 +65,11 @@ struct crt_ctx {
     uint32_t* dTileOrder = nullptr;
     uint32_t* hTileOrder[2] = {nullptr, nullptr}; hipEvent_t orderCopied[2] = {nullptr, nullptr}; hipEvent_t orderReady = nullptr; int orderFlip = 0;
     bool haveScene = false;
+    // what crt_update_scene needs of the last upload: a host mirror of the geometry buffer and where each BVH's records start
+    struct Flat { int32_t kind = 0; uint64_t leafOff = 0, tlasOff = 0, tlasPairOff = 0, instOff = 0, shadeOff = 0; uint32_t tlasNodeCount = 0, maxHeight = 0;
+                  std::vector<uint64_t> pairBase, triBase; std::vector<uint32_t> nodesUsed, triCount; std::vector<char> geom; } flat;
+    char* hStage[2] = {nullptr, nullptr}; size_t stageBytes[2] = {0, 0}; hipEvent_t stageCopied[2] = {nullptr, nullptr}; int stageFlip = 0;
+    hipEvent_t sceneReady = nullptr;      // recorded behind the last in-place scene update; render launches wait for it on their stream
     void* dQueryRays = nullptr; void* dQueryHits = nullptr; size_t queryCap = 0;      // crt_find_nearest staging (rays)
     uint32_t poolMinFrames = 65;  // launches of fewer frames (one stream per lane) run render_tiles_kernel
     bool usePool = true;          // render_pool_kernel (stream pool); CRT_RENDER_KERNEL=tiles selects render_tiles_kernel (one stream per lane)
@@ -238,6 +243,7 @@ void crt_destroy(crt_ctx* c)
     if (c->dQueryRays) (void)hipFree(c->dQueryRays);
     if (c->dQueryHits) (void)hipFree(c->dQueryHits);
     for (int k = 0; k < 2; k++) { if (c->hTileOrder[k]) (void)hipHostFree(c->hTileOrder[k]); if (c->orderCopied[k]) (void)hipEventDestroy(c->orderCopied[k]); }
+    for (int k = 0; k < 2; k++) { if (c->hStage[k]) (void)hipHostFree(c->hStage[k]); if (c->stageCopied[k]) (void)hipEventDestroy(c->stageCopied[k]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -492,7 +498,141 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         else grow(sd->bvhs[0].nodes[0].aabbMin, sd->bvhs[0].nodes[0].aabbMax);
         memcpy(c->meshLo, lo, 12); memcpy(c->meshHi, hi, 12); c->orderDirty = true;
     }
+    {   // keep what crt_update_scene needs
+        crt_ctx::Flat& f = c->flat;
+        f.kind = sd->kind; f.leafOff = leafOffB; f.tlasOff = tlasOffB; f.tlasPairOff = tlasPairOffB; f.instOff = instOffB; f.shadeOff = shadeOffB;
+        f.tlasNodeCount = (sd->kind == CRT_SCENE_TLAS) ? sd->tlasNodeCount : 0; f.maxHeight = maxHeight;
+        f.pairBase.clear(); f.triBase.clear(); f.nodesUsed.clear(); f.triCount.clear();
+        uint64_t pb = 0, tb = 0;
+        for (uint32_t bi = 0; bi < sd->bvhCount; bi++) { f.pairBase.push_back(pb); f.triBase.push_back(tb); f.nodesUsed.push_back(sd->bvhs[bi].nodesUsed); f.triCount.push_back(sd->bvhs[bi].triCount); pb += sd->bvhs[bi].nodesUsed / 2; tb += sd->bvhs[bi].triCount; }
+        f.geom.swap(geom);
+    }
     c->haveScene = true;
+    return CRT_OK;
+}
+
+// fills the TLAS sections of a host geometry image from the reference's TLASBVHNode array: per-node records with both reference forms, and the child
+// pair of every interior node side by side (NodePair layout).  Returns the TLAS height, or a negative status.
+static int flatten_tlas(crt_ctx* c, const crt_tlas_node* nodes, uint32_t count, uint32_t bvhCount, crt::TlasNode* tlas, crt::NodePair* tlasPairs, uint32_t* heightOut)
+{
+    uint32_t nTlasPairs = 0;
+    for (uint32_t i = 0; i < count; i++) {      // device copy carries each node's packed reference instead of leftRight / BLAS
+        const crt_tlas_node& nd = nodes[i];
+        memcpy(tlas[i].lo, nd.aabbMin, 12); memcpy(tlas[i].hi, nd.aabbMax, 12);
+        tlas[i].ref = nd.leftRight ? (crt::kRefTlasInterior | (nd.leftRight & 0x7fffu) | (((nd.leftRight >> 16) & 0x7fffu) << 15))
+                                   : (crt::kRefTlasLeaf | (nd.BLAS & 0xffffu));
+        tlas[i].ref16 = nd.leftRight ? (crt::kRef16TlasBit | nTlasPairs++) : (crt::kRef16TlasLeaf | (nd.BLAS & crt::kRef16IndexMask));   // interior nodes number their child pairs
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 0u}); size_t visited = 0; uint32_t height = 0;
+    while (!st.empty()) {
+        auto [n, d] = st.back(); st.pop_back();
+        if (++visited > (size_t)count) return c->fail(CRT_ERR_INVALID, "TLAS node graph is not a tree");
+        const crt_tlas_node& nd = nodes[n];
+        if (nd.leftRight == 0) { if (nd.BLAS >= bvhCount) return c->fail(CRT_ERR_INVALID, "TLAS leaf references BLAS %u", nd.BLAS); if (d > height) height = d; continue; }
+        const uint32_t l = nd.leftRight & 0xffffu, r = nd.leftRight >> 16;
+        if (l >= count || r >= count) return c->fail(CRT_ERR_INVALID, "TLAS child index out of range");
+        st.push_back({l, d + 1}); st.push_back({r, d + 1});
+    }
+    for (uint32_t i = 0; i < count; i++) {
+        const crt_tlas_node& nd = nodes[i];
+        if (nd.leftRight == 0) continue;
+        crt::NodePair& p = tlasPairs[tlas[i].ref16 & crt::kRef16IndexMask];
+        memcpy(&p.c[0], &tlas[nd.leftRight & 0xffffu], 32); memcpy(&p.c[1], &tlas[nd.leftRight >> 16], 32);
+    }
+    *heightOut = height;
+    return 0;
+}
+
+// the Scene block's view of the root: its child pair travels in the kernel arguments (see render kernels), plus the dispatch-order bounds
+static void set_root(crt_ctx* c, int kind, const float* lo, const float* hi)
+{
+    crt::Scene& s = c->hScene; const crt_ctx::Flat& f = c->flat;
+    s.rootIsPair = 0; memset(s.rootPair, 0, sizeof(s.rootPair));
+    if (kind == CRT_SCENE_TLAS) {
+        const crt::TlasNode* tlas = reinterpret_cast<const crt::TlasNode*>(f.geom.data() + f.tlasOff);
+        const uint32_t root = tlas[0].ref;
+        s.rootRef = root; s.rootRef16 = tlas[0].ref16;
+        if ((root & 0xC0000000u) == crt::kRefTlasInterior) { memcpy(s.rootPair, &tlas[root & 0x7fffu], 32); memcpy(s.rootPair + 8, &tlas[(root >> 15) & 0x7fffu], 32); s.rootIsPair = 1; }
+    } else if (s.rootRef & crt::kRefInterior) {
+        memcpy(s.rootPair, f.geom.data() + ((size_t)(s.rootRef & crt::kRefOffsetMask) << 4), 64);
+        s.rootIsPair = 1;
+    }
+    if (getenv("CRT_DEBUG_NO_ROOTPAIR")) s.rootIsPair = 0;
+    memcpy(c->meshLo, lo, 12); memcpy(c->meshHi, hi, 12); c->orderDirty = true;
+}
+
+int crt_update_scene(crt_ctx* c, const crt_scene_desc* sd, uint32_t what)
+{
+    if (!c || !sd) return CRT_ERR_INVALID;
+    if (!c->haveScene) return c->fail(CRT_ERR_STATE, "crt_update_scene before crt_upload_scene");
+    crt_ctx::Flat& f = c->flat;
+    if (sd->kind != f.kind || sd->bvhCount != f.nodesUsed.size() || !sd->bvhs) return c->fail(CRT_ERR_INVALID, "crt_update_scene: scene kind / BVH count differ from the uploaded scene");
+    if ((what & ~(uint32_t)(CRT_UPDATE_TRANSFORMS | CRT_UPDATE_BOUNDS)) || what == 0) return c->fail(CRT_ERR_INVALID, "crt_update_scene: unknown update flags");
+    if ((what & CRT_UPDATE_TRANSFORMS) && f.kind != CRT_SCENE_TLAS) return c->fail(CRT_ERR_INVALID, "CRT_UPDATE_TRANSFORMS applies to two-level scenes (a FileScene bakes its transforms into the triangles)");
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    for (uint32_t bi = 0; bi < sd->bvhCount; bi++)
+        if (sd->bvhs[bi].nodesUsed != f.nodesUsed[bi] || sd->bvhs[bi].triCount != f.triCount[bi] || !sd->bvhs[bi].nodes || !sd->bvhs[bi].triangles || !sd->bvhs[bi].triangleIndices)
+            return c->fail(CRT_ERR_INVALID, "crt_update_scene: BVH %u changed its topology (node / triangle count); upload the scene again", bi);
+    size_t lo = SIZE_MAX, hi = 0;                                         // byte range of the geometry buffer to rewrite
+    auto touch = [&](size_t a, size_t b) { if (a < lo) lo = a; if (b > hi) hi = b; };
+    if (what & CRT_UPDATE_BOUNDS) {
+        // BVH::Refit / BLASBVH::Refit (bvh.cpp:26-43): same tree, new boxes and vertex positions.  References, leaf order and shading records stay.
+        crt::NodePair* pairs = reinterpret_cast<crt::NodePair*>(f.geom.data());
+        crt::LeafTri* leaf = reinterpret_cast<crt::LeafTri*>(f.geom.data() + f.leafOff);
+        for (uint32_t bi = 0; bi < sd->bvhCount; bi++) {
+            const crt_bvh& b = sd->bvhs[bi];
+            for (uint32_t n = 1; n + 1 < b.nodesUsed; n += 2) {
+                crt::NodePair& p = pairs[f.pairBase[bi] + ((n - 1) >> 1)];
+                for (int k = 0; k < 2; k++) { memcpy(p.c[k].lo, b.nodes[n + k].aabbMin, 12); memcpy(p.c[k].hi, b.nodes[n + k].aabbMax, 12); }
+            }
+            for (uint32_t j = 0; j < b.triCount; j++) {
+                const uint32_t ti = b.triangleIndices[j];
+                if (ti >= b.triCount) return c->fail(CRT_ERR_INVALID, "BVH %u: triangleIndices[%u] out of range", bi, j);
+                const crt_tri& t = b.triangles[ti];
+                crt::LeafTri& lt = leaf[f.triBase[bi] + j];
+                if (lt.shadeIdx != (uint32_t)(f.triBase[bi] + ti)) return c->fail(CRT_ERR_INVALID, "BVH %u: triangleIndices changed; Refit keeps the leaf order — upload the scene again", bi);
+                for (int k = 0; k < 3; k++) { lt.v0[k] = t.vertex0[k]; lt.e1[k] = t.vertex1[k] - t.vertex0[k]; lt.e2[k] = t.vertex2[k] - t.vertex0[k]; }
+            }
+        }
+        touch(0, (size_t)f.tlasOff);
+    }
+    uint32_t tlasHeight = 0;
+    if (f.kind == CRT_SCENE_TLAS) {
+        if (what & CRT_UPDATE_TRANSFORMS) {
+            if (!sd->tlasNodes || sd->tlasNodeCount != f.tlasNodeCount) return c->fail(CRT_ERR_INVALID, "crt_update_scene: TLAS node count differs from the uploaded scene");
+            crt::Instance* inst = reinterpret_cast<crt::Instance*>(f.geom.data() + f.instOff);
+            for (uint32_t bi = 0; bi < sd->bvhCount; bi++) { memcpy(inst[bi].invT, sd->bvhs[bi].invT, 48); memcpy(inst[bi].T, sd->bvhs[bi].T, 48); }   // BLASBVH::SetTransform, blas_bvh.cpp:363-374
+        }
+        // TLASBVH::Build (tlas_bvh.cpp:17-55) ran on the host after SetTransform / Refit: new node array of the same size
+        if (sd->tlasNodes && sd->tlasNodeCount == f.tlasNodeCount) {
+            int r = flatten_tlas(c, sd->tlasNodes, sd->tlasNodeCount, sd->bvhCount, reinterpret_cast<crt::TlasNode*>(f.geom.data() + f.tlasOff),
+                                 reinterpret_cast<crt::NodePair*>(f.geom.data() + f.tlasPairOff), &tlasHeight);
+            if (r) return r;
+            touch((size_t)f.tlasOff, (size_t)f.shadeOff);
+            crt::Scene& s = c->hScene;
+            s.stackDepth = s.bvhStack + tlasHeight + 1;
+            c->ldsBytes = s.stackDepth * 64u * 4u;
+            if (c->ldsBytes + 15u * 256u > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "TLAS height %u needs %u bytes of LDS traversal stack per wave (> 64 KiB)", tlasHeight, c->ldsBytes);
+        }
+    }
+    if (lo >= hi) return CRT_OK;
+    // In-place rewrite, no allocation of device memory and no host wait for the GPU: the copy runs on the main stream, which is ordered behind every
+    // render launch submitted so far (it waits for each launch's end event before that launch's accumulate); launches submitted later wait
+    // for `sceneReady` on their own stream.  Pinned staging buffers alternate and grow on demand; one is reused only after its own copy.
+    const int k = c->stageFlip ^= 1;
+    const size_t bytes = hi - lo;
+    if (c->stageBytes[k] < bytes) {
+        if (c->hStage[k]) { HIPCK(c, hipEventSynchronize(c->stageCopied[k])); HIPCK(c, hipHostFree(c->hStage[k])); c->hStage[k] = nullptr; }
+        HIPCK(c, hipHostMalloc((void**)&c->hStage[k], bytes, hipHostMallocDefault)); c->stageBytes[k] = bytes;
+        if (!c->stageCopied[k]) HIPCK(c, hipEventCreateWithFlags(&c->stageCopied[k], hipEventDisableTiming));
+    } else HIPCK(c, hipEventSynchronize(c->stageCopied[k]));
+    memcpy(c->hStage[k], f.geom.data() + lo, bytes);
+    HIPCK(c, hipMemcpyAsync(const_cast<char*>(c->hScene.geom) + lo, c->hStage[k], bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipEventRecord(c->stageCopied[k], c->stream));
+    c->sceneReady = c->stageCopied[k];
+    const float* blo = (f.kind == CRT_SCENE_TLAS) ? sd->tlasNodes[0].aabbMin : sd->bvhs[0].nodes[0].aabbMin;
+    const float* bhi = (f.kind == CRT_SCENE_TLAS) ? sd->tlasNodes[0].aabbMax : sd->bvhs[0].nodes[0].aabbMax;
+    set_root(c, f.kind, blo, bhi);
     return CRT_OK;
 }
 
@@ -688,6 +828,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         size_t off = 0; int r;
         if ((r = take_region(c, (size_t)((nf + 63u) / 64u) * windowBytes, st, &off))) return r;
         if (c->orderReady) HIPCK(c, hipStreamWaitEvent(st, c->orderReady, 0));
+        if (c->sceneReady) HIPCK(c, hipStreamWaitEvent(st, c->sceneReady, 0));
         void* slab = c->pool + off;
         EventPair ev;
         fold_completed(c, c->evRender, &c->foldedRenderMs, &c->foldedLaunches); fold_completed(c, c->evAcc, &c->foldedAccMs, nullptr);

@@ -91,6 +91,28 @@ int crt_host_scene_bvh_move_and_refit(crt_host_scene* s, int i, const float* pos
     return CRT_OK;
     GUARD_END(CRT_ERR_INVALID)
 }
+// BLASBVH::SetTransform(T) of instance i (blas_bvh.cpp:363-374: T, invT = FastInvertedTransformNoScale, world bounds of the 8 root-box corners)
+// followed by TLASBVH::Build (tlas_bvh.cpp:17-55), as an animation loop does per frame; crt_host_scene_update then moves it to the device
+int crt_host_scene_set_transform(crt_host_scene* s, int i, const float T[16])
+{
+    if (!s || !T) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    if (!s->tlas || i < 0 || i >= (int)s->tlas->tlas.blas.size()) { g_err = "not a TLAS scene / index out of range (a FileScene bakes its transforms into the triangles)"; return CRT_ERR_INVALID; }
+    GUARD_BEGIN
+    mat4 m; memcpy(m.cell, T, 64);
+    s->tlas->tlas.blas[(size_t)i]->SetTransform(m);
+    s->tlas->tlas.Build();
+    return CRT_OK;
+    GUARD_END(CRT_ERR_INVALID)
+}
+int crt_host_scene_update(crt_host_scene* s, crt_ctx* ctx, uint32_t what)
+{
+    if (!s || !ctx) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    GUARD_BEGIN
+    const int rc = s->scene->Update(ctx, what);
+    if (rc != CRT_OK) g_err = crt_last_error(ctx);
+    return rc;
+    GUARD_END(CRT_ERR_DEVICE)
+}
 int crt_host_scene_blas_transform(crt_host_scene* s, int i, float T[16], float invT[16], float lo[3], float hi[3])
 {
     if (!s || !s->tlas || i < 0 || i >= (int)s->tlas->tlas.blas.size()) { g_err = "not a TLAS scene / index out of range"; return CRT_ERR_INVALID; }

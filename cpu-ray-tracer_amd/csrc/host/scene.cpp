@@ -57,30 +57,44 @@ float3 BaseScene::GetLightPos() const   // file_scene.cpp:156-162
     return (c1 + c2) * 0.5f - float3(0, 0.01f, 0);
 }
 
-int BaseScene::Upload(crt_ctx* ctx)
+// crt_scene_desc of the built scene (borrowed pointers into this object and into `k`, which must outlive the call that uses the description)
+void BaseScene::BuildDesc(crt_scene_desc& d, DescKeep& k)
 {
-    crt_scene_desc d; memset(&d, 0, sizeof(d));
-    std::vector<crt_bvh> bvhs; std::vector<int32_t> objMat;
-    Describe(d, bvhs, objMat);
+    memset(&d, 0, sizeof(d));
+    Describe(d, k.bvhs, k.objMat);
     d.kind = Kind();
-    d.bvhs = bvhs.data(); d.bvhCount = (uint32_t)bvhs.size();
-    d.objMatIdx = objMat.empty() ? nullptr : objMat.data(); d.objCount = (uint32_t)objMat.size();
-    std::vector<crt_material> mats(materials.size());
+    d.bvhs = k.bvhs.data(); d.bvhCount = (uint32_t)k.bvhs.size();
+    d.objMatIdx = k.objMat.empty() ? nullptr : k.objMat.data(); d.objCount = (uint32_t)k.objMat.size();
+    k.mats.resize(materials.size());
     for (size_t i = 0; i < materials.size(); i++) {
-        mats[i].reflectivity = materials[i]->reflectivity; mats[i].refractivity = materials[i]->refractivity;
-        mats[i].absorption[0] = materials[i]->absorption.x; mats[i].absorption[1] = materials[i]->absorption.y; mats[i].absorption[2] = materials[i]->absorption.z;
-        mats[i].texture = materials[i]->texture;
+        k.mats[i].reflectivity = materials[i]->reflectivity; k.mats[i].refractivity = materials[i]->refractivity;
+        k.mats[i].absorption[0] = materials[i]->absorption.x; k.mats[i].absorption[1] = materials[i]->absorption.y; k.mats[i].absorption[2] = materials[i]->absorption.z;
+        k.mats[i].texture = materials[i]->texture;
     }
-    d.materials = mats.data(); d.materialCount = (uint32_t)mats.size();
-    std::vector<crt_texture> tex(textures.size());
-    for (size_t i = 0; i < textures.size(); i++) { tex[i].pixels = textures[i].pixels.data(); tex[i].width = textures[i].width; tex[i].height = textures[i].height; }
-    d.textures = tex.data(); d.textureCount = (uint32_t)tex.size();
+    d.materials = k.mats.data(); d.materialCount = (uint32_t)k.mats.size();
+    k.tex.resize(textures.size());
+    for (size_t i = 0; i < textures.size(); i++) { k.tex[i].pixels = textures[i].pixels.data(); k.tex[i].width = textures[i].width; k.tex[i].height = textures[i].height; }
+    d.textures = k.tex.data(); d.textureCount = (uint32_t)k.tex.size();
     d.floorTexture = 0; d.skyTexture = 1;
     memcpy(d.lightT, lightT.cell, 64); memcpy(d.lightInvT, lightInvT.cell, 64); d.lightSize = lightSize;
     d.floorN[0] = floorN.x; d.floorN[1] = floorN.y; d.floorN[2] = floorN.z; d.floorD = floorD; d.floorInvto = floorInvto;
+}
+
+int BaseScene::Upload(crt_ctx* ctx)
+{
+    crt_scene_desc d; DescKeep k;
+    BuildDesc(d, k);
     const int rc = crt_upload_scene(ctx, &d);
     if (rc == CRT_OK) bound = ctx;
     return rc;
+}
+
+// after BLASBVH::SetTransform + TLASBVH::Build (CRT_UPDATE_TRANSFORMS) or Refit (CRT_UPDATE_BOUNDS): rewrites only those sections on the device
+int BaseScene::Update(crt_ctx* ctx, uint32_t what)
+{
+    crt_scene_desc d; DescKeep k;
+    BuildDesc(d, k);
+    return crt_update_scene(ctx, &d, what);
 }
 
 void BaseScene::FindNearest(Ray& ray)

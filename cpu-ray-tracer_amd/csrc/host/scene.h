@@ -38,6 +38,8 @@ public:
     virtual ~BaseScene() = default;
     // flattens and uploads the built scene to the device context (the one call the reference's classes lack)
     int Upload(crt_ctx* ctx);
+    // in-place device update after instance motion (BLASBVH::SetTransform + TLASBVH::Build) / Refit: crt_update_scene with this scene's description
+    int Update(crt_ctx* ctx, uint32_t what);
     // scene.FindNearest(ray): one ray through crt_find_nearest (use the batch ABI for many)
     void FindNearest(Ray& ray);
     float3 GetLightPos() const;
@@ -56,6 +58,8 @@ public:
 protected:
     void LoadCommon(const SceneData& sd, const std::string& baseDir);
     virtual void Describe(crt_scene_desc& d, std::vector<crt_bvh>& bvhs, std::vector<int32_t>& objMat) = 0;
+    struct DescKeep { std::vector<crt_bvh> bvhs; std::vector<int32_t> objMat; std::vector<crt_material> mats; std::vector<crt_texture> tex; };
+    void BuildDesc(crt_scene_desc& d, DescKeep& keep);
     crt_ctx* bound = nullptr;
 };
 

@@ -142,6 +142,16 @@ const char* crt_last_error(crt_ctx* ctx);                      /* ctx may be NUL
 
 /* ---- scene / camera (lower seam) -------------------------------------------------------------------- */
 int  crt_upload_scene(crt_ctx* ctx, const crt_scene_desc* scene);   /* flattens to the device layout and copies; host pointers are not kept */
+/* In-place update of an uploaded scene for animation (renderer.cpp:147 `animating`), same description as at upload, same topology:
+ *   CRT_UPDATE_TRANSFORMS  two-level scenes: every BLAS's T / invT as BLASBVH::SetTransform left them (blas_bvh.cpp:363-374) and the node array of the
+ *                          TLASBVH::Build that followed (tlas_bvh.cpp:17-55) — instance motion;
+ *   CRT_UPDATE_BOUNDS      every BVH's node boxes and triangle vertices as BVH::Refit / BLASBVH::Refit left them (bvh.cpp:26-43; node / triangle counts,
+ *                          child indices and triangleIndices unchanged) and, for two-level scenes, the rebuilt TLAS.
+ * Only the affected sections of the device geometry buffer are rewritten (a few KB for transforms): no device allocation, no host wait for the GPU;
+ * frames submitted earlier still see the old scene, frames submitted later the new one. */
+#define CRT_UPDATE_TRANSFORMS 1u
+#define CRT_UPDATE_BOUNDS     2u
+int  crt_update_scene(crt_ctx* ctx, const crt_scene_desc* scene, uint32_t what);
 int  crt_set_camera(crt_ctx* ctx, const float camPos[3], const float topLeft[3], const float topRight[3], const float bottomLeft[3]);
                                                                 /* Camera members used by GetPrimaryRay (camera.h:23-30) */
 

@@ -41,6 +41,10 @@ int  crt_host_scene_bvh_copy(crt_host_scene* scene, int bvh, crt_bvh_node* nodes
  * re-derives the instance's world bounds (SetTransform, blas_bvh.cpp:363-374) and rebuilds the TLAS (tlas_bvh.cpp:17-70).  Call
  * crt_host_scene_upload again afterwards: the device layout is re-flattened from the refitted arrays. */
 int  crt_host_scene_bvh_move_and_refit(crt_host_scene* scene, int bvh, const float* positions, uint32_t triCount);
+/* instance motion: BLASBVH::SetTransform(T) of BLAS `bvh` (infra/blas_bvh.cpp:363-374) + TLASBVH::Build (infra/tlas_bvh.cpp:17-55) on the host ... */
+int  crt_host_scene_set_transform(crt_host_scene* scene, int bvh, const float T[16]);
+/* ... and the in-place device update for it (what = CRT_UPDATE_TRANSFORMS) or for crt_host_scene_bvh_move_and_refit (what = CRT_UPDATE_BOUNDS): crt_update_scene */
+int  crt_host_scene_update(crt_host_scene* scene, crt_ctx* ctx, uint32_t what);
 int  crt_host_scene_blas_transform(crt_host_scene* scene, int bvh, float T[16], float invT[16], float worldMin[3], float worldMax[3]);
 int  crt_host_scene_tlas_copy(crt_host_scene* scene, crt_tlas_node* nodes /* 2*blasCount */, uint32_t* nodesUsed);
 

@@ -982,6 +982,14 @@ int orc_bvh_move_and_refit(orc_ctx* c, int i, const float* positions, uint32_t t
     if (c->kind == 1) { b->set_transform(b->T); if (!c->tlas.build(c->err)) return -1; }
     return 0;
 }
+// instance motion: BLASBVH::SetTransform(T) (blas_bvh.cpp:363-374) of BLAS i, then TLASBVH::Build (tlas_bvh.cpp:17-55) — what an animation loop does per frame
+int orc_set_blas_transform(orc_ctx* c, int i, const float T[16])
+{
+    if (!c->built || c->kind != 1 || i < 0 || i >= (int)c->bvhs.size()) return -1;
+    M4 m; memcpy(m.c, T, 64);
+    c->bvhs[i]->set_transform(m);
+    return c->tlas.build(c->err) ? 0 : -1;
+}
 int orc_blas_transform(orc_ctx* c, int i, float T[16], float invT[16], float lo[3], float hi[3])
 {
     if (i < 0 || i >= (int)c->bvhs.size()) return -1;

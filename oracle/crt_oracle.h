@@ -70,6 +70,7 @@ int orc_build(orc_ctx*);
 int orc_bvh_count(orc_ctx*);
 int orc_bvh_info(orc_ctx*, int bvh, uint32_t* nodesUsed, uint32_t* triCount, uint32_t* maxDepth);
 int orc_bvh_copy(orc_ctx*, int bvh, orc_bvh_node* nodes /*nodesUsed*/, uint32_t* triIndices /*triCount*/, orc_tri* tris /*triCount*/);
+int orc_set_blas_transform(orc_ctx*, int bvh, const float T[16]);   /* BLASBVH::SetTransform + TLASBVH::Build */
 int orc_bvh_move_and_refit(orc_ctx*, int bvh, const float* positions /* 9 floats per triangle */, uint32_t triCount);   /* BVH::Refit, bvh.cpp:26-43 */
 int orc_blas_transform(orc_ctx*, int bvh, float T[16], float invT[16], float worldMin[3], float worldMax[3]);
 int orc_tlas_copy(orc_ctx*, orc_tlas_node* nodes /*2*blasCount*/, uint32_t* nodesUsed);

@@ -169,6 +169,11 @@ class Oracle:
         self._ck(self.L.orc_blas_transform(self.h, i, _fp(T), _fp(invT), _fp(lo), _fp(hi)))
         return T, invT, lo, hi
 
+    def set_transform(self, i, T):
+        """BLASBVH::SetTransform(T) of instance i + TLASBVH::Build"""
+        T = np.ascontiguousarray(T, np.float32).reshape(16)
+        self._ck(self.L.orc_set_blas_transform(self.h, int(i), _fp(T)))
+
     def move_and_refit(self, i, positions):
         positions = np.ascontiguousarray(positions, np.float32)
         self._ck(self.L.orc_bvh_move_and_refit(self.h, i, _fp(positions), C.c_uint32(positions.shape[0])))

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Cost of one animation step behind the boundary: BLASBVH::SetTransform + TLASBVH::Build on the host, crt_update_scene
+(in-place rewrite of the TLAS / instance sections), one Tick.  Usage: python tools/update_cost.py [scene.xml W H]"""
+import importlib.util, os, sys, time
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))
+crt = importlib.util.module_from_spec(spec); spec.loader.exec_module(crt)
+A = os.path.join(REPO, "assets")
+xml = sys.argv[1] if len(sys.argv) > 1 else "tlas_scene.xml"
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 1280
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 720
+hs = crt.HostScene(os.path.join(A, "scenes", xml), 1, A)
+ctx = crt.Context(W, H); hs.upload(ctx); ctx.render(1, 1, 1); ctx.sync()
+T0 = hs.blas_transform(0)[0].reshape(4, 4).copy()
+host, upd, full, tick = [], [], [], []
+for f in range(30):
+    T = T0.copy(); a = np.float32(0.05 * f); T[0, 0] = np.cos(a); T[0, 2] = np.sin(a); T[2, 0] = -np.sin(a); T[2, 2] = np.cos(a)
+    t0 = time.perf_counter(); hs.set_transform(0, T); t1 = time.perf_counter()
+    hs.update(ctx, crt.UPDATE_TRANSFORMS); t2 = time.perf_counter()
+    ctx.clear(); ctx.render(1 + f, 1, 1); ctx.sync(); t3 = time.perf_counter()
+    host.append(t1 - t0); upd.append(t2 - t1); tick.append(t3 - t2)
+for f in range(5):
+    t0 = time.perf_counter(); hs.upload(ctx); ctx.sync(); full.append(time.perf_counter() - t0)
+med = lambda v: sorted(v)[len(v) // 2] * 1e3
+print("%s %dx%d, %d BLAS: SetTransform + TLASBVH::Build %.3f ms | crt_update_scene(TRANSFORMS) %.3f ms | one Tick after it %.2f ms | full crt_upload_scene for comparison %.1f ms"
+      % (xml, W, H, hs.bvh_count(), med(host), med(upd), med(tick), med(full)))
