@@ -21,6 +21,9 @@ LIB_PATH = os.environ.get("CRT_LIB_PATH") or os.path.join(HERE, "libcrt_amd.so")
 
 SCENE_FILE, SCENE_TLAS = 0, 1
 UPDATE_TRANSFORMS, UPDATE_BOUNDS = 1, 2        # crt_update_scene flags
+ACCEL_KDTREE, ACCEL_GRID = 1, 2                 # FileScene's alternative accelerators (crt_upload_alt_accel / crt_find_nearest_alt)
+KD_NODE_DTYPE = np.dtype([("aabbMin", "<f4", 3), ("left", "<i4"), ("aabbMax", "<f4", 3), ("right", "<i4"), ("splitDistance", "<f4"), ("splitAxis", "<i4"),
+                          ("firstTri", "<u4"), ("triCount", "<u4")])      # crt_kd_node
 
 
 class CrtError(RuntimeError):
@@ -74,10 +77,10 @@ RAY_DTYPE = np.dtype([("O", "<f4", 3), ("D", "<f4", 3), ("inside", "<i4")])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("objIdx", "<i4"), ("triIdx", "<i4"), ("traversed", "<i4"), ("tested", "<i4")])
 
 # every symbol include/crt_abi.h and include/crt_host.h declare (tests check the library exports all of them)
-ABI_SYMBOLS = ["crt_update_scene", "crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
+ABI_SYMBOLS = ["crt_upload_alt_accel", "crt_find_nearest_alt", "crt_update_scene", "crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
                "crt_render", "crt_reserve", "crt_whitted_tick", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
                "crt_reset_counters", "crt_get_timing", "crt_get_tile_clocks", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
-HOST_SYMBOLS = ["crt_host_scene_set_transform", "crt_host_scene_update", "crt_host_math_probe", "crt_host_vertex_dedup", "crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
+HOST_SYMBOLS = ["crt_host_scene_build_alt", "crt_host_scene_upload_alt", "crt_host_scene_alt_info", "crt_host_scene_alt_copy", "crt_host_scene_set_transform", "crt_host_scene_update", "crt_host_math_probe", "crt_host_vertex_dedup", "crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
                 "crt_host_scene_triangle_count", "crt_host_scene_bvh_count", "crt_host_scene_bvh_info", "crt_host_scene_bvh_copy",
                 "crt_host_scene_bvh_move_and_refit", "crt_host_scene_blas_transform", "crt_host_scene_tlas_copy", "crt_host_camera_state", "crt_host_renderer_create",
                 "crt_host_renderer_destroy", "crt_host_renderer_init", "crt_host_renderer_set_camera", "crt_host_renderer_set_passes",
@@ -211,6 +214,14 @@ class Context:
         self._ck(self.L.crt_resolve_screen(self.h, C.c_float(scale), _p(px), C.byref(e)))
         return px, e.value
 
+    def find_nearest_alt(self, kind, O, D):
+        """scene.FindNearest with FileScene's KD-tree / grid in place of the BVH (crt_find_nearest_alt)"""
+        O = np.ascontiguousarray(O, np.float32).reshape(-1, 3); D = np.ascontiguousarray(D, np.float32).reshape(-1, 3)
+        rays = np.zeros(O.shape[0], RAY_DTYPE); rays["O"] = O; rays["D"] = D
+        hits = np.zeros(O.shape[0], HIT_DTYPE)
+        self._ck(self.L.crt_find_nearest_alt(self.h, int(kind), _p(rays), _p(hits), C.c_size_t(O.shape[0])))
+        return hits
+
     def upload_desc(self, kind, bvhs, textures, floor_texture, sky_texture, materials, light_T, light_invT, light_size=0.5,
                     floor_n=(0, 1, 0), floor_d=1.0, floor_invto=None, obj_mat_idx=None, tlas_nodes=None):
         """crt_upload_scene with arrays BUILT ELSEWHERE, in the reference's own layouts (INTEGRATION.md path A): bvhs = dicts with `nodes` (32-byte BVHNode
@@ -334,6 +345,23 @@ class HostScene:
         """BVH::Refit for moved vertices: positions = (triCount, 3, 3) floats in the reference's triangle order; upload() again afterwards"""
         positions = np.ascontiguousarray(positions, np.float32)
         self._ck(self.L.crt_host_scene_bvh_move_and_refit(self.h, int(i), _p(positions), C.c_uint32(positions.shape[0])))
+
+    def build_alt(self, kind):
+        """KDTree::Build / Grid::Build over the FileScene's triangles on the host; returns the flattened structure (the layout crt_upload_alt_accel takes)"""
+        self._ck(self.L.crt_host_scene_build_alt(self.h, int(kind)))
+        info = (C.c_uint32 * 4)()
+        self._ck(self.L.crt_host_scene_alt_info(self.h, int(kind), info))
+        if kind == ACCEL_KDTREE:
+            nodes = np.zeros(info[0], KD_NODE_DTYPE); refs = np.zeros(max(info[1], 1), np.uint32)
+            self._ck(self.L.crt_host_scene_alt_copy(self.h, int(kind), _p(nodes), _p(refs), None))
+            return dict(nodes=nodes, refs=refs[:info[1]], maxDepth=int(info[2]), nodesUsed=int(info[3]))
+        res = np.array([info[0], info[1], info[2]], np.int32)
+        start = np.zeros(int(res.prod()) + 1, np.uint32); refs = np.zeros(max(info[3], 1), np.int32); f = np.zeros(9, np.float32)
+        self._ck(self.L.crt_host_scene_alt_copy(self.h, int(kind), _p(start), _p(refs), _p(f)))
+        return dict(resolution=res, cellSize=f[0:3].copy(), boundsMin=f[3:6].copy(), boundsMax=f[6:9].copy(), cellStart=start, refs=refs[:info[3]])
+
+    def upload_alt(self, ctx, kind):
+        self._ck(self.L.crt_host_scene_upload_alt(self.h, ctx.h, int(kind)))
 
     def set_transform(self, i, T):
         """BLASBVH::SetTransform(T) of instance i (T = 4x4 row-major, rigid) + TLASBVH::Build on the host; update(ctx, UPDATE_TRANSFORMS) moves it to the device"""

@@ -28,6 +28,17 @@ static_assert(sizeof(crt_bvh_node) == 32 && sizeof(crt_tri) == 112 && sizeof(crt
 static_assert(sizeof(crt::NodePair) == 64 && sizeof(crt::LeafTri) == 48 && sizeof(crt::ShadeTri) == 64 && sizeof(crt::TlasNode) == 32 &&
               sizeof(crt::Instance) == 128 && sizeof(crt::Material) == 32 && offsetof(crt::Instance, T) == 64, "device layouts");
 static_assert(sizeof(crt_counters) == sizeof(crt::Counters), "counter layout");
+static_assert(sizeof(crt_kd_node) == 48, "flat KD node");
+// device view of the alternative accelerators (device/alt_accel.hip)
+namespace crt {
+struct KdNode; struct AltTri;
+struct AltAccelDev {
+    const void* kdNodes; const uint32_t* kdRefs; uint32_t kdStack;
+    const void* tris;
+    int32_t res[3]; float cell[3]; float lo[3], hi[3]; const uint32_t* cellStart; const int32_t* cellRefs;
+};
+}
+extern "C" hipError_t crt_launch_find_nearest_alt(int, const crt::Scene*, const crt::AltAccelDev*, const void*, void*, uint32_t, hipStream_t);
 
 namespace {
 
@@ -70,6 +81,7 @@ struct crt_ctx {
                   std::vector<uint64_t> pairBase, triBase; std::vector<uint32_t> nodesUsed, triCount; std::vector<char> geom; } flat;
     char* hStage[2] = {nullptr, nullptr}; size_t stageBytes[2] = {0, 0}; hipEvent_t stageCopied[2] = {nullptr, nullptr}; int stageFlip = 0;
     hipEvent_t sceneReady = nullptr;      // recorded behind the last in-place scene update; render launches wait for it on their stream
+    crt::AltAccelDev alt{}; bool haveKd = false, haveGrid = false; std::vector<void*> altAllocs[2]; void* altTris = nullptr; uint32_t altTriCount = 0;   // KD-tree [0] / grid [1] buffers
     void* dQueryRays = nullptr; void* dQueryHits = nullptr; size_t queryCap = 0;      // crt_find_nearest staging (rays)
     uint32_t poolMinFrames = 65;  // launches of fewer frames (one stream per lane) run render_tiles_kernel
     bool usePool = true;          // render_pool_kernel (stream pool); CRT_RENDER_KERNEL=tiles selects render_tiles_kernel (one stream per lane)
@@ -90,10 +102,17 @@ struct crt_ctx {
         if (e == hipSuccess) return 0;
         return fail(CRT_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
     }
+    void freeAlt()
+    {
+        for (auto& v : altAllocs) { for (void* p : v) (void)hipFree(p); v.clear(); }
+        if (altTris) (void)hipFree(altTris);
+        altTris = nullptr; altTriCount = 0; haveKd = haveGrid = false; alt = crt::AltAccelDev{};
+    }
     void freeScene()
     {
         for (void* p : sceneAllocs) (void)hipFree(p);
         sceneAllocs.clear(); haveScene = false;
+        freeAlt();                        // the alternative accelerators index the scene's triangles
     }
 };
 
@@ -929,6 +948,102 @@ int crt_find_nearest(crt_ctx* c, const crt_ray* rays, crt_hit* hits, size_t n)
     HIPCK(c, hipMemcpyAsync(dR, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, crt_launch_find_nearest(&c->hScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->stream));
     HIPCK(c, hipMemcpyAsync(hits, dH, n * sizeof(crt_hit), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+// FileScene's KD-tree / uniform grid over the scene's triangles, for crt_find_nearest_alt
+int crt_upload_alt_accel(crt_ctx* c, const crt_alt_accel* a)
+{
+    if (!c || !a) return CRT_ERR_INVALID;
+    if (!c->haveScene || c->hScene.kind != CRT_SCENE_FILE) return c->fail(CRT_ERR_STATE, "crt_upload_alt_accel needs an uploaded CRT_SCENE_FILE scene (light quad, floor plane, materials)");
+    if (a->kind != CRT_ACCEL_KDTREE && a->kind != CRT_ACCEL_GRID) return c->fail(CRT_ERR_INVALID, "unknown accelerator kind %d", a->kind);
+    if (!a->triangles || a->triCount == 0) return c->fail(CRT_ERR_INVALID, "accelerator has no triangles");
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    const int slot = a->kind == CRT_ACCEL_KDTREE ? 0 : 1;
+    uint32_t kdHeight = 0;
+    if (a->kind == CRT_ACCEL_KDTREE) {
+        if (!a->kdNodes || a->kdNodeCount == 0 || (a->kdTriIndexCount && !a->kdTriIndices)) return c->fail(CRT_ERR_INVALID, "KD-tree arrays missing");
+        std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({0u, 0u}); size_t visited = 0;
+        while (!st.empty()) {
+            auto [n, d] = st.back(); st.pop_back();
+            if (++visited > (size_t)a->kdNodeCount) return c->fail(CRT_ERR_INVALID, "KD node graph is not a tree");
+            const crt_kd_node& nd = a->kdNodes[n];
+            if (d > kdHeight) kdHeight = d;
+            if (nd.left < 0) { if ((uint64_t)nd.firstTri + nd.triCount > a->kdTriIndexCount) return c->fail(CRT_ERR_INVALID, "KD leaf %u: triangle range out of bounds", n); continue; }
+            if (nd.right < 0 || (uint32_t)nd.left >= a->kdNodeCount || (uint32_t)nd.right >= a->kdNodeCount || nd.splitAxis < 0 || nd.splitAxis > 2)
+                return c->fail(CRT_ERR_INVALID, "KD node %u: child index / split axis out of range", n);
+            st.push_back({(uint32_t)nd.left, d + 1}); st.push_back({(uint32_t)nd.right, d + 1});
+        }
+        for (uint32_t i = 0; i < a->kdTriIndexCount; i++) if (a->kdTriIndices[i] >= a->triCount) return c->fail(CRT_ERR_INVALID, "kdTriIndices[%u] out of range", i);
+        if ((kdHeight + 1) * 128u * 4u > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "KD-tree height %u exceeds the LDS traversal stack", kdHeight);
+    } else {
+        uint64_t cells = 1;
+        for (int k = 0; k < 3; k++) { if (a->gridResolution[k] < 1 || a->gridResolution[k] > 128) return c->fail(CRT_ERR_INVALID, "grid resolution must be 1..128 per axis (grid.cpp:22)"); cells *= (uint64_t)a->gridResolution[k]; }
+        if (!a->gridCellStart || (a->gridCellTriCount && !a->gridCellTris)) return c->fail(CRT_ERR_INVALID, "grid arrays missing");
+        if (a->gridCellStart[0] != 0 || a->gridCellStart[cells] != a->gridCellTriCount) return c->fail(CRT_ERR_INVALID, "gridCellStart must run from 0 to gridCellTriCount");
+        for (uint64_t i = 0; i < cells; i++) if (a->gridCellStart[i] > a->gridCellStart[i + 1]) return c->fail(CRT_ERR_INVALID, "gridCellStart is not monotone at cell %llu", (unsigned long long)i);
+        for (uint32_t i = 0; i < a->gridCellTriCount; i++) if (a->gridCellTris[i] < 0 || (uint32_t)a->gridCellTris[i] >= a->triCount) return c->fail(CRT_ERR_INVALID, "gridCellTris[%u] out of range", i);
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));                            // queries of the previous structure
+    for (void* p : c->altAllocs[slot]) (void)hipFree(p);
+    c->altAllocs[slot].clear();
+    if (slot == 0) c->haveKd = false; else c->haveGrid = false;
+    auto up = [&](const void* src, size_t bytes, const void** out) -> int {
+        *out = nullptr; if (!bytes) return 0;
+        void* d = nullptr; HIPCK(c, hipMalloc(&d, bytes)); c->altAllocs[slot].push_back(d);
+        HIPCK(c, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice)); *out = d; return 0;
+    };
+    int r;
+    // Möller–Trumbore operands in the reference's triangle order (one array shared by both structures)
+    if (!c->altTris || c->altTriCount != a->triCount) {
+        if (c->altTris) { (void)hipFree(c->altTris); c->altTris = nullptr; }
+        HIPCK(c, hipMalloc(&c->altTris, (size_t)a->triCount * 48)); c->altTriCount = a->triCount;
+    }
+    {
+        std::vector<float> rec((size_t)a->triCount * 12);
+        for (uint32_t i = 0; i < a->triCount; i++) {
+            const crt_tri& t = a->triangles[i]; float* o = &rec[(size_t)i * 12];
+            for (int k = 0; k < 3; k++) { o[k] = t.vertex0[k]; o[4 + k] = t.vertex1[k] - t.vertex0[k]; o[8 + k] = t.vertex2[k] - t.vertex0[k]; }
+            memcpy(&o[3], &i, 4); memcpy(&o[7], &t.objIdx, 4); o[11] = 0;
+        }
+        HIPCK(c, hipMemcpy(c->altTris, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+        c->alt.tris = c->altTris;
+    }
+    if (slot == 0) {
+        if ((r = up(a->kdNodes, (size_t)a->kdNodeCount * 48, &c->alt.kdNodes))) return r;
+        const void* p = nullptr; if ((r = up(a->kdTriIndices, (size_t)a->kdTriIndexCount * 4, &p))) return r;
+        c->alt.kdRefs = (const uint32_t*)p; c->alt.kdStack = kdHeight + 1; c->haveKd = true;
+    } else {
+        uint64_t cells = (uint64_t)a->gridResolution[0] * a->gridResolution[1] * a->gridResolution[2];
+        const void* p = nullptr;
+        if ((r = up(a->gridCellStart, (size_t)(cells + 1) * 4, &p))) return r; c->alt.cellStart = (const uint32_t*)p;
+        if ((r = up(a->gridCellTris, (size_t)a->gridCellTriCount * 4, &p))) return r; c->alt.cellRefs = (const int32_t*)p;
+        for (int k = 0; k < 3; k++) { c->alt.res[k] = a->gridResolution[k]; c->alt.cell[k] = a->gridCellSize[k]; c->alt.lo[k] = a->gridMin[k]; c->alt.hi[k] = a->gridMax[k]; }
+        c->haveGrid = true;
+    }
+    return CRT_OK;
+}
+
+int crt_find_nearest_alt(crt_ctx* c, int kind, const crt_ray* rays, crt_hit* hits, size_t n)
+{
+    if (!c || (n && (!rays || !hits))) return CRT_ERR_INVALID;
+    if (!((kind == CRT_ACCEL_KDTREE && c->haveKd) || (kind == CRT_ACCEL_GRID && c->haveGrid))) return c->fail(CRT_ERR_STATE, "crt_find_nearest_alt: no such accelerator uploaded (kind %d)", kind);
+    if (n == 0) return CRT_OK;
+    if (n > 0x7fffffffull) return c->fail(CRT_ERR_UNSUPPORTED, "at most 2^31-1 rays per call");
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (n > c->queryCap) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (c->dQueryRays) (void)hipFree(c->dQueryRays);
+        if (c->dQueryHits) (void)hipFree(c->dQueryHits);
+        c->dQueryRays = c->dQueryHits = nullptr; c->queryCap = 0;
+        HIPCK(c, hipMalloc(&c->dQueryRays, n * sizeof(crt_ray)));
+        HIPCK(c, hipMalloc(&c->dQueryHits, n * sizeof(crt_hit)));
+        c->queryCap = n;
+    }
+    HIPCK(c, hipMemcpyAsync(c->dQueryRays, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, crt_launch_find_nearest_alt(kind, &c->hScene, &c->alt, c->dQueryRays, c->dQueryHits, (uint32_t)n, c->stream));
+    HIPCK(c, hipMemcpyAsync(hits, c->dQueryHits, n * sizeof(crt_hit), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
 }

@@ -1,6 +1,7 @@
 // host_abi.cpp — C wrappers (include/crt_host.h) around the C++ host front.  Exceptions stop here.
 #include "../../../include/crt_host.h"
 #include "scene.h"
+#include "accel_alt.h"
 
 #include <cstdlib>
 #include <string>
@@ -9,7 +10,7 @@ using namespace crt;
 
 namespace { thread_local std::string g_err; }
 
-struct crt_host_scene { BaseScene* scene = nullptr; FileScene* file = nullptr; TLASFileScene* tlas = nullptr; };
+struct crt_host_scene { BaseScene* scene = nullptr; FileScene* file = nullptr; TLASFileScene* tlas = nullptr; KDTree* kd = nullptr; Grid* grid = nullptr; };
 struct crt_host_renderer { Renderer* r = nullptr; };
 
 #define GUARD_BEGIN try {
@@ -35,7 +36,7 @@ int crt_host_scene_load(const char* xml, int kind, const char* base, crt_host_sc
     return CRT_OK;
     GUARD_END(CRT_ERR_IO)
 }
-void crt_host_scene_free(crt_host_scene* s) { if (s) { delete s->scene; delete s; } }
+void crt_host_scene_free(crt_host_scene* s) { if (s) { delete s->scene; delete s->kd; delete s->grid; delete s; } }
 int crt_host_scene_upload(crt_host_scene* s, crt_ctx* ctx)
 {
     if (!s || !ctx) { g_err = "null argument"; return CRT_ERR_INVALID; }
@@ -195,6 +196,65 @@ int crt_host_image_load(const char* path, int* w, int* h, uint32_t** pixels)
     GUARD_END(CRT_ERR_IO)
 }
 void crt_host_free(void* p) { free(p); }
+
+// FileScene's alternative accelerators (file_scene.h:10-12: USE_KDTree is what the reference ships): built over the scene's triangle array on the host
+int crt_host_scene_build_alt(crt_host_scene* s, int kind)
+{
+    if (!s || !s->file) { g_err = "alternative accelerators belong to a FileScene"; return CRT_ERR_INVALID; }
+    GUARD_BEGIN
+    if (kind == CRT_ACCEL_KDTREE) { delete s->kd; s->kd = new KDTree(); s->kd->triangles = s->file->acc.triangles; s->kd->Build(); }
+    else if (kind == CRT_ACCEL_GRID) { delete s->grid; s->grid = new Grid(); s->grid->triangles = s->file->acc.triangles; s->grid->Build(); }
+    else { g_err = "unknown accelerator kind"; return CRT_ERR_INVALID; }
+    return CRT_OK;
+    GUARD_END(CRT_ERR_INVALID)
+}
+static int describe_alt(crt_host_scene* s, int kind, crt_alt_accel& a)
+{
+    memset(&a, 0, sizeof(a)); a.kind = kind;
+    if (kind == CRT_ACCEL_KDTREE && s->kd) {
+        a.triangles = s->kd->triangles.data(); a.triCount = (uint32_t)s->kd->triangles.size();
+        a.kdNodes = s->kd->nodes.data(); a.kdNodeCount = (uint32_t)s->kd->nodes.size(); a.kdTriIndices = s->kd->leafTriIndices.data(); a.kdTriIndexCount = (uint32_t)s->kd->leafTriIndices.size();
+        return CRT_OK;
+    }
+    if (kind == CRT_ACCEL_GRID && s->grid) {
+        const Grid& g = *s->grid;
+        a.triangles = g.triangles.data(); a.triCount = (uint32_t)g.triangles.size();
+        for (int k = 0; k < 3; k++) { a.gridResolution[k] = g.resolution[k]; a.gridCellSize[k] = g.cellSize[k]; a.gridMin[k] = g.localBounds.bmin3[k]; a.gridMax[k] = g.localBounds.bmax3[k]; }
+        a.gridCellStart = g.cellStart.data(); a.gridCellTris = g.cellTris.data(); a.gridCellTriCount = (uint32_t)g.cellTris.size();
+        return CRT_OK;
+    }
+    g_err = "accelerator not built (crt_host_scene_build_alt)"; return CRT_ERR_STATE;
+}
+int crt_host_scene_upload_alt(crt_host_scene* s, crt_ctx* ctx, int kind)
+{
+    if (!s || !ctx) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    crt_alt_accel a; int rc = describe_alt(s, kind, a); if (rc) return rc;
+    rc = crt_upload_alt_accel(ctx, &a);
+    if (rc != CRT_OK) g_err = crt_last_error(ctx);
+    return rc;
+}
+// sizes: KD-tree -> {nodes, leaf triangle indices, maxDepth, nodesUsed}; grid -> {rx, ry, rz, cell triangle references}
+int crt_host_scene_alt_info(crt_host_scene* s, int kind, uint32_t out[4])
+{
+    if (!s || !out) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    crt_alt_accel a; int rc = describe_alt(s, kind, a); if (rc) return rc;
+    if (kind == CRT_ACCEL_KDTREE) { out[0] = a.kdNodeCount; out[1] = a.kdTriIndexCount; out[2] = s->kd->maxDepth; out[3] = s->kd->nodesUsed; }
+    else { out[0] = (uint32_t)a.gridResolution[0]; out[1] = (uint32_t)a.gridResolution[1]; out[2] = (uint32_t)a.gridResolution[2]; out[3] = a.gridCellTriCount; }
+    return CRT_OK;
+}
+// copies: KD-tree -> nodes (48 B each) + leaf triangle indices; grid -> f[0..2] cellSize, f[3..5] bounds min, f[6..8] bounds max, cellStart (cells + 1), cell triangle references
+int crt_host_scene_alt_copy(crt_host_scene* s, int kind, void* nodesOrCellStart, void* refs, float* f9)
+{
+    if (!s) { g_err = "null argument"; return CRT_ERR_INVALID; }
+    crt_alt_accel a; int rc = describe_alt(s, kind, a); if (rc) return rc;
+    if (kind == CRT_ACCEL_KDTREE) { if (nodesOrCellStart) memcpy(nodesOrCellStart, a.kdNodes, (size_t)a.kdNodeCount * 48); if (refs) memcpy(refs, a.kdTriIndices, (size_t)a.kdTriIndexCount * 4); }
+    else {
+        const size_t cells = (size_t)a.gridResolution[0] * a.gridResolution[1] * a.gridResolution[2];
+        if (nodesOrCellStart) memcpy(nodesOrCellStart, a.gridCellStart, (cells + 1) * 4); if (refs) memcpy(refs, a.gridCellTris, (size_t)a.gridCellTriCount * 4);
+        if (f9) for (int k = 0; k < 3; k++) { f9[k] = a.gridCellSize[k]; f9[3 + k] = a.gridMin[k]; f9[6 + k] = a.gridMax[k]; }
+    }
+    return CRT_OK;
+}
 
 // test entries: the host front's restatements of the tmplmath.h inlines / the Vertex table, same layout as the real-reference harness's probes (tests/golden/make_golden.py)
 void crt_host_math_probe(const float* in, uint32_t n, float* out)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 1
+#define CRT_ABI_VERSION 2
 
 typedef enum crt_status {
     CRT_OK = 0,
@@ -179,6 +179,33 @@ int  crt_whitted_tick(crt_ctx* ctx, uint32_t* host_pixels /* width*height or NUL
 
 /* ---- query entry = scene.FindNearest(ray) ------------------------------------------------------------ */
 int  crt_find_nearest(crt_ctx* ctx, const crt_ray* rays, crt_hit* hits, size_t n);
+
+/* ---- FileScene's alternative accelerators: KDTree (infra/kdtree.cpp — the one the reference ships enabled, infra/scene/file_scene.h:10-12)
+ * and Grid (infra/grid.cpp), built on the host exactly as there and attached to an uploaded CRT_SCENE_FILE scene.  The reference's KDTreeNode is
+ * pointer-linked with a std::vector per node (infra/blas_kdtree.h:15-24), so there is no layout to be bit-compatible with: nodes are passed flattened in
+ * PRE-ORDER (node, left subtree, right subtree), leaves naming a range of kdTriIndices; Grid's cells (x-major: ix + iy*rx + iz*rx*ry) as a prefix array.
+ * crt_find_nearest_alt = scene.FindNearest with that accelerator in place of the BVH (light quad, floor plane, accelerator: file_scene.cpp:170-175);
+ * crt_hit.traversed / tested count as Ray::traversed / Ray::tested do there.  The render kernels walk the SAH-BVH only. */
+#define CRT_ACCEL_KDTREE 1
+#define CRT_ACCEL_GRID   2
+typedef struct crt_kd_node {
+    float aabbMin[3]; int32_t left;          /* KDTreeNode::aabbMin; index of node->left, < 0 = leaf (isLeaf)                    */
+    float aabbMax[3]; int32_t right;
+    float splitDistance; int32_t splitAxis;  /* interior: splitPos = aabbMin[splitAxis] + splitDistance (kdtree.cpp:161-162)       */
+    uint32_t firstTri, triCount;             /* leaf: triIndices = kdTriIndices[firstTri .. firstTri + triCount)                    */
+} crt_kd_node;
+typedef struct crt_alt_accel {
+    int32_t kind;                                                    /* CRT_ACCEL_KDTREE or CRT_ACCEL_GRID                          */
+    const crt_tri* triangles; uint32_t triCount;                     /* KDTree::triangles / Grid::triangles (= FileScene's triangle array) */
+    const crt_kd_node* kdNodes; uint32_t kdNodeCount;                /* KD-tree: pre-order nodes, root = 0                          */
+    const uint32_t* kdTriIndices; uint32_t kdTriIndexCount;
+    int32_t gridResolution[3]; float gridCellSize[3];                /* Grid::resolution, cellSize                                  */
+    float gridMin[3], gridMax[3];                                    /* Grid::localBounds                                           */
+    const uint32_t* gridCellStart;                                   /* rx*ry*rz + 1 entries: cell c holds gridCellTris[start[c] .. start[c+1]) */
+    const int32_t* gridCellTris; uint32_t gridCellTriCount;
+} crt_alt_accel;
+int  crt_upload_alt_accel(crt_ctx* ctx, const crt_alt_accel* accel);   /* after crt_upload_scene of a CRT_SCENE_FILE scene; one structure per kind is kept */
+int  crt_find_nearest_alt(crt_ctx* ctx, int kind, const crt_ray* rays, crt_hit* hits, size_t n);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
 int  crt_get_counters(crt_ctx* ctx, crt_counters* out);        /* cumulative since create / crt_reset_counters       */

@@ -41,6 +41,13 @@ int  crt_host_scene_bvh_copy(crt_host_scene* scene, int bvh, crt_bvh_node* nodes
  * re-derives the instance's world bounds (SetTransform, blas_bvh.cpp:363-374) and rebuilds the TLAS (tlas_bvh.cpp:17-70).  Call
  * crt_host_scene_upload again afterwards: the device layout is re-flattened from the refitted arrays. */
 int  crt_host_scene_bvh_move_and_refit(crt_host_scene* scene, int bvh, const float* positions, uint32_t triCount);
+/* FileScene's alternative accelerators (infra/scene/file_scene.h:10-12 selects one at compile time, KDTree as shipped): KDTree::Build
+ * (infra/kdtree.cpp:4-107) / Grid::Build (infra/grid.cpp:4-50) over the scene's triangles on the host, upload through crt_upload_alt_accel, queries through
+ * crt_find_nearest_alt.  kind = CRT_ACCEL_KDTREE / CRT_ACCEL_GRID. */
+int  crt_host_scene_build_alt(crt_host_scene* scene, int kind);
+int  crt_host_scene_upload_alt(crt_host_scene* scene, crt_ctx* ctx, int kind);
+int  crt_host_scene_alt_info(crt_host_scene* scene, int kind, uint32_t out[4]);   /* KD: nodes, leaf indices, maxDepth, nodesUsed; grid: rx, ry, rz, cell references */
+int  crt_host_scene_alt_copy(crt_host_scene* scene, int kind, void* nodesOrCellStart, void* refs, float* gridCellMinMax9);
 /* instance motion: BLASBVH::SetTransform(T) of BLAS `bvh` (infra/blas_bvh.cpp:363-374) + TLASBVH::Build (infra/tlas_bvh.cpp:17-55) on the host ... */
 int  crt_host_scene_set_transform(crt_host_scene* scene, int bvh, const float T[16]);
 /* ... and the in-place device update for it (what = CRT_UPDATE_TRANSFORMS) or for crt_host_scene_bvh_move_and_refit (what = CRT_UPDATE_BOUNDS): crt_update_scene */

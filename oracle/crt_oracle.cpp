@@ -1286,6 +1286,189 @@ int orc_png_unfilter(const uint8_t* raw, uint8_t* out, int stride, int h, int fb
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Alternative accelerators of FileScene: KDTree (infra/kdtree.cpp — the shipped default, file_scene.h:10-12) and Grid (infra/grid.cpp).
+// Restated on flat arrays; the tree is numbered in pre-order (node, left subtree, right subtree).  Pinned to the real reference through
+// oracle/_ref (ref_kd_* / ref_grid_*) and tests/golden/ref_alt_accel.npz.
+// ------------------------------------------------------------------------------------------------
+namespace {
+// Möller–Trumbore of kdtree.cpp:122-141 / grid.cpp:63-82 (the same arithmetic as bvh.cpp:203-222)
+static inline void alt_hit_tri(Ray& r, const Tri& tri, uint ti)
+{
+    V3 v0 = ld3(tri.vertex0);
+    V3 e1 = ld3(tri.vertex1) - v0, e2 = ld3(tri.vertex2) - v0;
+    V3 h = cross(r.D, e2);
+    float a = dot(e1, h);
+    if (a > -0.0001f && a < 0.0001f) return;
+    float f = 1 / a;
+    V3 s = r.O - v0;
+    float u = f * dot(s, h);
+    if (u < 0 || u > 1) return;
+    V3 q = cross(s, e1);
+    float v = f * dot(r.D, q);
+    if (v < 0 || u + v > 1) return;
+    float t = f * dot(e2, q);
+    if (t > 0.0001f) { if (t < r.t) { r.t = smin_(r.t, t); r.objIdx = tri.objIdx; r.triIdx = (int)ti; r.bu = u; r.bv = v; } }
+}
+static inline bool alt_hit_aabb(const Ray& r, V3 lo, V3 hi, float& tminOut, float& tmaxOut)   // kdtree.cpp:109-120, grid.cpp:52-61
+{
+    float tx1 = (lo.x - r.O.x) * r.rD.x, tx2 = (hi.x - r.O.x) * r.rD.x;
+    float tmin = smin_(tx1, tx2), tmax = smax_(tx1, tx2);
+    float ty1 = (lo.y - r.O.y) * r.rD.y, ty2 = (hi.y - r.O.y) * r.rD.y;
+    tmin = smax_(tmin, smin_(ty1, ty2)); tmax = smin_(tmax, smax_(ty1, ty2));
+    float tz1 = (lo.z - r.O.z) * r.rD.z, tz2 = (hi.z - r.O.z) * r.rD.z;
+    tmin = smax_(tmin, smin_(tz1, tz2)); tmax = smin_(tmax, smax_(tz1, tz2));
+    tminOut = tmin; tmaxOut = tmax;
+    return tmax >= tmin && tmin < r.t && tmax > 0;
+}
+static inline void setcomp(V3& v, int a, float x) { if (a == 0) v.x = x; else if (a == 1) v.y = x; else v.z = x; }
+
+struct KdTree {
+    std::vector<Tri> tris; std::vector<Box> triBounds;
+    std::vector<orc_kd_node> nodes; std::vector<uint32_t> refs;
+    uint32_t maxDepth = 0, nodesUsed = 1;
+    // kdtree.cpp:45-107: spatial median of the longest axis, stop at depth 20 or <= 2 triangles; straddling triangles go to both sides
+    uint32_t subdivide(V3 lo, V3 hi, std::vector<uint>& idx, int depth)
+    {
+        const uint32_t me = (uint32_t)nodes.size();
+        nodes.push_back(orc_kd_node());
+        { orc_kd_node& n = nodes[me]; st3(n.aabbMin, lo); st3(n.aabbMax, hi); n.left = n.right = -1; n.splitAxis = 0; n.splitDistance = 0; n.firstTri = (uint32_t)refs.size(); n.triCount = 0; }
+        const uint triCount = (uint)idx.size();
+        bool leaf = depth >= 20 || triCount <= 2;
+        if (!leaf) {
+            if ((uint32_t)depth > maxDepth) maxDepth = (uint32_t)depth;
+            V3 extent = hi - lo;
+            int axis = 0;
+            if (extent.y > extent.x) axis = 1;
+            if (extent.z > comp(extent, axis)) axis = 2;
+            float distance = comp(extent, axis) * 0.5f;
+            float splitPos = comp(lo, axis) + distance;
+            std::vector<uint> L, R;
+            for (uint i = 0; i < triCount; i++) {
+                uint t = idx[i];
+                if (comp(triBounds[t].hi, axis) < splitPos) L.push_back(t);
+                else if ((double)comp(triBounds[t].lo, axis) > (double)splitPos - 0.001) R.push_back(t);     // `splitPos - 0.001` is a double expression
+                else { L.push_back(t); R.push_back(t); }
+            }
+            nodesUsed += 2;
+            V3 lhi = hi, rlo = lo; setcomp(lhi, axis, splitPos); setcomp(rlo, axis, splitPos);
+            idx.clear(); idx.shrink_to_fit();
+            const uint32_t l = subdivide(lo, lhi, L, depth + 1), r = subdivide(rlo, hi, R, depth + 1);
+            orc_kd_node& n = nodes[me]; n.left = (int32_t)l; n.right = (int32_t)r; n.splitAxis = axis; n.splitDistance = distance;
+        } else {
+            orc_kd_node& n = nodes[me]; n.firstTri = (uint32_t)refs.size(); n.triCount = triCount;
+            refs.insert(refs.end(), idx.begin(), idx.end());
+        }
+        return me;
+    }
+    void build()   // kdtree.cpp:4-43
+    {
+        triBounds.resize(tris.size());
+        Box b;
+        for (size_t i = 0; i < tris.size(); i++) { Box tb; tb.grow(ld3(tris[i].vertex0)); tb.grow(ld3(tris[i].vertex1)); tb.grow(ld3(tris[i].vertex2)); b.grow(tb); triBounds[i] = tb; }
+        std::vector<uint> all(tris.size()); for (size_t i = 0; i < tris.size(); i++) all[i] = (uint)i;
+        subdivide(b.lo, b.hi, all, 0);
+    }
+    void intersect(Ray& r, int ni) const   // kdtree.cpp:143-202
+    {
+        const orc_kd_node& n = nodes[ni];
+        float tmin, tmax;
+        r.traversed++;
+        if (!alt_hit_aabb(r, ld3(n.aabbMin), ld3(n.aabbMax), tmin, tmax)) return;
+        if (n.left < 0) { for (uint i = 0; i < n.triCount; i++) { uint ti = refs[n.firstTri + i]; alt_hit_tri(r, tris[ti], ti); r.tested++; } return; }
+        const int axis = n.splitAxis;
+        const float splitPos = n.aabbMin[axis] + n.splitDistance;
+        const float t = (splitPos - comp(r.O, axis)) / comp(r.D, axis);
+        const int first = comp(r.D, axis) > 0 ? n.left : n.right, second = comp(r.D, axis) > 0 ? n.right : n.left;
+        if ((double)t < (double)tmin + 0.001) intersect(r, second);              // the plane lies before the box: only the far side
+        else if ((double)t > (double)tmax - 0.001) intersect(r, first);          // ... behind the box: only the near side
+        else { intersect(r, first); if (r.t < t) return; intersect(r, second); }
+    }
+};
+
+struct UGrid {
+    std::vector<Tri> tris; int res[3] = {0, 0, 0}; V3 cell = v3(0.0f); Box bounds;
+    std::vector<uint32_t> cellStart; std::vector<int32_t> refs;
+    static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }     // tmplmath clamp(int)
+    void build()   // grid.cpp:4-50
+    {
+        for (const Tri& t : tris) { Box tb; tb.grow(ld3(t.vertex0)); tb.grow(ld3(t.vertex1)); tb.grow(ld3(t.vertex2)); bounds.grow(tb); }
+        V3 size = bounds.hi - bounds.lo;
+        float cubeRoot = powf(5 * (int)tris.size() / (size.x * size.y * size.z), 1 / 3.f);
+        for (int i = 0; i < 3; i++) { int r = (int)floorf(comp(size, i) * cubeRoot); res[i] = std::max(1, std::min(r, 128)); }
+        cell = v3(size.x / res[0], size.y / res[1], size.z / res[2]);
+        std::vector<std::vector<int32_t>> cells((size_t)res[0] * res[1] * res[2]);
+        for (size_t ti = 0; ti < tris.size(); ti++) {
+            Box b; b.grow(ld3(tris[ti].vertex0)); b.grow(ld3(tris[ti].vertex1)); b.grow(ld3(tris[ti].vertex2));
+            int mn[3], mx[3];
+            for (int k = 0; k < 3; k++) {
+                mn[k] = clampi((int)((comp(b.lo, k) - comp(bounds.lo, k)) / comp(cell, k)), 0, res[k] - 1);
+                mx[k] = clampi((int)((comp(b.hi, k) - comp(bounds.lo, k)) / comp(cell, k)), 0, res[k] - 1);
+            }
+            for (int iz = mn[2]; iz <= mx[2]; ++iz) for (int iy = mn[1]; iy <= mx[1]; ++iy) for (int ix = mn[0]; ix <= mx[0]; ++ix)
+                cells[(size_t)ix + (size_t)iy * res[0] + (size_t)iz * res[0] * res[1]].push_back((int32_t)ti);
+        }
+        cellStart.clear(); refs.clear();
+        for (auto& c : cells) { cellStart.push_back((uint32_t)refs.size()); refs.insert(refs.end(), c.begin(), c.end()); }
+        cellStart.push_back((uint32_t)refs.size());
+    }
+    void intersect(Ray& r) const   // grid.cpp:89-153 (3D-DDA; mailboxing is compiled out in the reference)
+    {
+        float tmn, tmx;
+        if (!alt_hit_aabb(r, bounds.lo, bounds.hi, tmn, tmx)) return;
+        int exitc[3], step[3], c[3]; float deltaT[3], next[3];
+        for (int i = 0; i < 3; ++i) {
+            float rayOrigCell = comp(r.O, i) - comp(bounds.lo, i);
+            c[i] = clampi((int)floorf(rayOrigCell / comp(cell, i)), 0, res[i] - 1);
+            if (comp(r.D, i) < 0) { deltaT[i] = -comp(cell, i) * comp(r.rD, i); next[i] = (c[i] * comp(cell, i) - rayOrigCell) * comp(r.rD, i); exitc[i] = -1; step[i] = -1; }
+            else { deltaT[i] = comp(cell, i) * comp(r.rD, i); next[i] = ((c[i] + 1) * comp(cell, i) - rayOrigCell) * comp(r.rD, i); exitc[i] = res[i]; step[i] = 1; }
+        }
+        for (;;) {
+            r.traversed++;
+            const uint32_t index = (uint32_t)c[0] + (uint32_t)c[1] * res[0] + (uint32_t)c[2] * res[0] * res[1];
+            for (uint32_t k = cellStart[index]; k < cellStart[index + 1]; k++) { r.tested++; alt_hit_tri(r, tris[refs[k]], (uint)refs[k]); }
+            const uint k = ((next[0] < next[1]) << 2) + ((next[0] < next[2]) << 1) + ((next[1] < next[2]));
+            static const uint8_t map[8] = {2, 1, 2, 1, 2, 2, 0, 0};
+            const uint8_t axis = map[k];
+            if (r.t < next[axis]) break;
+            c[axis] += step[axis];
+            if (c[axis] == exitc[axis]) break;
+            next[axis] += deltaT[axis];
+        }
+    }
+};
+} // namespace
+
+void* orc_kd_build(const orc_tri* tris, uint32_t n) { KdTree* k = new KdTree(); k->tris.assign(tris, tris + n); k->build(); return k; }
+void orc_kd_info(void* h, uint32_t* nodes, uint32_t* refs, uint32_t* maxDepth, uint32_t* nodesUsed) { KdTree* k = (KdTree*)h; *nodes = (uint32_t)k->nodes.size(); *refs = (uint32_t)k->refs.size(); *maxDepth = k->maxDepth; *nodesUsed = k->nodesUsed; }
+void orc_kd_dump(void* h, orc_kd_node* nodes, uint32_t* refs) { KdTree* k = (KdTree*)h; memcpy(nodes, k->nodes.data(), k->nodes.size() * sizeof(orc_kd_node)); memcpy(refs, k->refs.data(), k->refs.size() * 4); }
+void orc_kd_intersect(void* h, const float* O, const float* D, uint32_t n, orc_hit* out)
+{
+    KdTree* k = (KdTree*)h;
+    for (uint32_t i = 0; i < n; i++) {
+        Ray r = make_ray(ld3(O + 3 * i), ld3(D + 3 * i));
+        k->intersect(r, 0);
+        out[i].t = r.t; out[i].u = r.bu; out[i].v = r.bv; out[i].objIdx = r.objIdx; out[i].triIdx = r.triIdx; out[i].traversed = r.traversed; out[i].tested = r.tested;
+    }
+}
+void orc_kd_free(void* h) { delete (KdTree*)h; }
+void* orc_grid_build(const orc_tri* tris, uint32_t n) { UGrid* g = new UGrid(); g->tris.assign(tris, tris + n); g->build(); return g; }
+void orc_grid_info(void* h, int32_t res[3], float cell[3], float lo[3], float hi[3], uint32_t* refs)
+{
+    UGrid* g = (UGrid*)h; for (int k = 0; k < 3; k++) res[k] = g->res[k]; st3(cell, g->cell); st3(lo, g->bounds.lo); st3(hi, g->bounds.hi); *refs = (uint32_t)g->refs.size();
+}
+void orc_grid_dump(void* h, uint32_t* cellStart, int32_t* refs) { UGrid* g = (UGrid*)h; memcpy(cellStart, g->cellStart.data(), g->cellStart.size() * 4); memcpy(refs, g->refs.data(), g->refs.size() * 4); }
+void orc_grid_intersect(void* h, const float* O, const float* D, uint32_t n, orc_hit* out)
+{
+    UGrid* g = (UGrid*)h;
+    for (uint32_t i = 0; i < n; i++) {
+        Ray r = make_ray(ld3(O + 3 * i), ld3(D + 3 * i));
+        g->intersect(r);
+        out[i].t = r.t; out[i].u = r.bu; out[i].v = r.bv; out[i].objIdx = r.objIdx; out[i].triIdx = r.triIdx; out[i].traversed = r.traversed; out[i].tested = r.tested;
+    }
+}
+void orc_grid_free(void* h) { delete (UGrid*)h; }
+
 // probes of the restated tmplmath.h / helper.h pieces, same layout as oracle/ref_build/ref_harness.cpp's ref_math_probe / ref_vertex_dedup
 void orc_math_probe(const float* in, uint32_t n, float* out)
 {

@@ -107,6 +107,18 @@ int orc_whitted_render(orc_ctx*, int n_threads);               /* one frame into
 int orc_png_unfilter(const uint8_t* raw, uint8_t* out, int stride, int h, int fb);
 
 /* deterministic math used for absorption / skydome lookups (see DESIGN.md "numerics") */
+/* alternative accelerators of FileScene (infra/kdtree.cpp, infra/grid.cpp), standalone over a triangle array; flat pre-order KD nodes */
+typedef struct orc_kd_node { float aabbMin[3]; int32_t left; float aabbMax[3]; int32_t right; float splitDistance; int32_t splitAxis; uint32_t firstTri, triCount; } orc_kd_node;   /* left < 0: leaf */
+void* orc_kd_build(const orc_tri* tris, uint32_t n);
+void orc_kd_info(void* h, uint32_t* nodes, uint32_t* refs, uint32_t* maxDepth, uint32_t* nodesUsed);
+void orc_kd_dump(void* h, orc_kd_node* nodes, uint32_t* refs);
+void orc_kd_intersect(void* h, const float* O, const float* D, uint32_t n, orc_hit* out);
+void orc_kd_free(void* h);
+void* orc_grid_build(const orc_tri* tris, uint32_t n);
+void orc_grid_info(void* h, int32_t res[3], float cell[3], float lo[3], float hi[3], uint32_t* refs);
+void orc_grid_dump(void* h, uint32_t* cellStart, int32_t* refs);
+void orc_grid_intersect(void* h, const float* O, const float* D, uint32_t n, orc_hit* out);
+void orc_grid_free(void* h);
 void orc_math_probe(const float* in12, uint32_t n, float* out120);
 uint32_t orc_vertex_dedup(const float* v8, uint32_t n, uint32_t* idx, float* unique8);
 float orc_expf(float x);

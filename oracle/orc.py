@@ -565,6 +565,50 @@ def load_scene(xml_path, kind, base_dir=None):
     return o, sc
 
 
+KD_NODE_DTYPE = np.dtype([("aabbMin", "<f4", 3), ("left", "<i4"), ("aabbMax", "<f4", 3), ("right", "<i4"), ("splitDistance", "<f4"), ("splitAxis", "<i4"),
+                          ("firstTri", "<u4"), ("triCount", "<u4")])      # flat pre-order KDTreeNode (left < 0: leaf), 48 bytes
+assert KD_NODE_DTYPE.itemsize == 48
+
+
+class AltAccel:
+    """KDTree (infra/kdtree.cpp) or Grid (infra/grid.cpp) over a triangle array: `L`/prefix select the oracle's restatement (orc_) or the real
+    reference compiled in place (ref_, oracle/_ref); same entry points, same flat layouts."""
+
+    def __init__(self, L, prefix, kind, tris):
+        self.L, self.p, self.kind = L, prefix + ("kd" if kind == "kd" else "grid"), kind
+        tris = np.ascontiguousarray(tris); assert tris.dtype.itemsize == 112
+        f = getattr(L, self.p + "_build"); f.restype = C.c_void_p
+        self.h = C.c_void_p(f(_fp(tris), C.c_uint32(len(tris))))
+
+    def dump(self):
+        if self.kind == "kd":
+            n, r, md, nu = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+            getattr(self.L, self.p + "_info")(self.h, C.byref(n), C.byref(r), C.byref(md), C.byref(nu))
+            nodes = np.zeros(n.value, KD_NODE_DTYPE); refs = np.zeros(max(r.value, 1), np.uint32)
+            getattr(self.L, self.p + "_dump")(self.h, _fp(nodes), _fp(refs))
+            return dict(nodes=nodes, refs=refs[:r.value], maxDepth=md.value, nodesUsed=nu.value)
+        res = np.zeros(3, np.int32); cell = np.zeros(3, np.float32); lo = np.zeros(3, np.float32); hi = np.zeros(3, np.float32); r = C.c_uint32()
+        getattr(self.L, self.p + "_info")(self.h, _fp(res), _fp(cell), _fp(lo), _fp(hi), C.byref(r))
+        start = np.zeros(int(res.prod()) + 1, np.uint32); refs = np.zeros(max(r.value, 1), np.int32)
+        getattr(self.L, self.p + "_dump")(self.h, _fp(start), _fp(refs))
+        return dict(resolution=res, cellSize=cell, boundsMin=lo, boundsMax=hi, cellStart=start, refs=refs[:r.value])
+
+    def intersect(self, O, D):
+        O = np.ascontiguousarray(O, np.float32).reshape(-1, 3); D = np.ascontiguousarray(D, np.float32).reshape(-1, 3)
+        hits = np.zeros(O.shape[0], HIT_DTYPE)
+        getattr(self.L, self.p + "_intersect")(self.h, _fp(O), _fp(D), C.c_uint32(O.shape[0]), _fp(hits))
+        return hits
+
+    def close(self):
+        if self.h:
+            getattr(self.L, self.p + "_free")(self.h); self.h = None
+
+
+def alt_accel(kind, tris):
+    """the oracle's KDTree ("kd") / Grid ("grid") over `tris`"""
+    return AltAccel(lib(), "orc_", kind, tris)
+
+
 def _math_probe(fn, inputs):
     inputs = np.ascontiguousarray(inputs, np.float32).reshape(-1, 12)
     out = np.zeros((len(inputs), 120), np.float32)
@@ -629,6 +673,10 @@ class Ref:
 
     def bvh_free(self, h):
         self.L.ref_bvh_free(h)
+
+    def alt_accel(self, kind, tris):
+        """the reference's own KDTree ("kd", infra/kdtree.cpp) / Grid ("grid", infra/grid.cpp), compiled in place"""
+        return AltAccel(self.L, "ref_", kind, tris)
 
     def math_probe(self, inputs):
         """the reference's inline tmplmath.h functions (normalize, reflect, cross, dot, mat4 factories, FastInvertedTransformNoScale, aabb): (n, 12) -> (n, 120)"""

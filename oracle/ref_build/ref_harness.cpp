@@ -3,6 +3,8 @@
  * never shipped, never loaded by the product).  Everything below the includes is glue: it fills the reference's
  * own containers, calls the reference's own functions and copies their results out.
  *   infra/bvh.cpp            -> BVH::Build, BVH::Refit, BVH::Intersect (IntersectBVH / IntersectAABB / IntersectTri)
+ *   infra/kdtree.cpp         -> KDTree::Build (spatial median, depth <= 20), KDTree::Intersect (recursive front-to-back traversal)
+ *   infra/grid.cpp           -> Grid::Build (uniform grid, <= 128^3 cells), Grid::Intersect (3D-DDA)
  *   lib/tiny_obj_loader.h    -> tinyobj::LoadObj (float parsing, quad / polygon triangulation)
  *   lib/stb_image.h          -> stbi_load (PNG / JPG / TGA decode)
  *   template/camera.h        -> Camera(): default frustum, GetPrimaryRay, SetCameraState (compiled for its fixed SCRWIDTH x SCRHEIGHT = 1024 x 640)
@@ -20,6 +22,8 @@
  */
 #include "precomp.h"
 #include "bvh.cpp"                     /* /root/reference/infra/bvh.cpp, unmodified */
+#include "kdtree.cpp"                  /* /root/reference/infra/kdtree.cpp, unmodified (the FileScene default accelerator, file_scene.h:10-12) */
+#include "grid.cpp"                    /* /root/reference/infra/grid.cpp, unmodified */
 
 #define STB_IMAGE_IMPLEMENTATION
 #define STBI_NO_PSD
@@ -85,6 +89,79 @@ void ref_bvh_intersect(void* h, const float* O, const float* D, uint32_t n, ref_
         out[i].objIdx = r.objIdx; out[i].triIdx = r.triIdx; out[i].traversed = r.traversed; out[i].tested = r.tested;
     }
 }
+
+/* ---- KDTree (infra/kdtree.cpp): flattened in PRE-ORDER (node, left subtree, right subtree); leaves list their triangle indices in a shared array ---- */
+void* ref_kd_build(const void* tris112, uint32_t n)
+{
+    KDTree* k = new KDTree();
+    k->triangles.resize(n);
+    memcpy((void*)k->triangles.data(), tris112, (size_t)n * sizeof(Tri));
+    k->Build();
+    return k;
+}
+static void kd_count(const KDTreeNode* nd, uint32_t& nodes, uint32_t& refs) { nodes++; if (nd->isLeaf) { refs += (uint32_t)nd->triIndices.size(); return; } kd_count(nd->left, nodes, refs); kd_count(nd->right, nodes, refs); }
+void ref_kd_info(void* h, uint32_t* nodes, uint32_t* refs, uint32_t* maxDepth, uint32_t* nodesUsed)
+{
+    KDTree* k = (KDTree*)h; *nodes = 0; *refs = 0; kd_count(k->rootNode, *nodes, *refs); *maxDepth = k->maxDepth; *nodesUsed = k->nodesUsed;
+}
+struct ref_kd_node { float aabbMin[3]; int32_t left; float aabbMax[3]; int32_t right; float splitDistance; int32_t splitAxis; uint32_t firstTri, triCount; };
+static uint32_t kd_flatten(const KDTreeNode* nd, ref_kd_node* out, uint32_t& next, uint32_t* refs, uint32_t& nrefs)
+{
+    const uint32_t me = next++;
+    ref_kd_node& o = out[me];
+    o.aabbMin[0] = nd->aabbMin.x; o.aabbMin[1] = nd->aabbMin.y; o.aabbMin[2] = nd->aabbMin.z; o.aabbMax[0] = nd->aabbMax.x; o.aabbMax[1] = nd->aabbMax.y; o.aabbMax[2] = nd->aabbMax.z;
+    o.splitDistance = nd->splitDistance; o.splitAxis = nd->splitAxis; o.firstTri = nrefs; o.triCount = 0; o.left = o.right = -1;
+    if (nd->isLeaf) { o.triCount = (uint32_t)nd->triIndices.size(); for (uint t : nd->triIndices) refs[nrefs++] = t; return me; }
+    const uint32_t l = kd_flatten(nd->left, out, next, refs, nrefs), r = kd_flatten(nd->right, out, next, refs, nrefs);
+    out[me].left = (int32_t)l; out[me].right = (int32_t)r;
+    return me;
+}
+void ref_kd_dump(void* h, void* nodes48, uint32_t* refs) { uint32_t next = 0, nrefs = 0; kd_flatten(((KDTree*)h)->rootNode, (ref_kd_node*)nodes48, next, refs, nrefs); }
+void ref_kd_intersect(void* h, const float* O, const float* D, uint32_t n, ref_hit* out)
+{
+    KDTree* k = (KDTree*)h;
+    for (uint32_t i = 0; i < n; i++) {
+        Ray r(float3(O[3 * i], O[3 * i + 1], O[3 * i + 2]), float3(D[3 * i], D[3 * i + 1], D[3 * i + 2]));
+        k->Intersect(r);
+        out[i].t = r.t; out[i].u = r.barycentric.x; out[i].v = r.barycentric.y;
+        out[i].objIdx = r.objIdx; out[i].triIdx = r.triIdx; out[i].traversed = r.traversed; out[i].tested = r.tested;
+    }
+}
+void ref_kd_free(void* h) { delete (KDTree*)h; }      /* (the reference never frees the nodes either) */
+
+/* ---- Grid (infra/grid.cpp): cells in x-major order (ix + iy * rx + iz * rx * ry), each with its triangle list ---- */
+void* ref_grid_build(const void* tris112, uint32_t n)
+{
+    Grid* g = new Grid();
+    g->triangles.resize(n);
+    memcpy((void*)g->triangles.data(), tris112, (size_t)n * sizeof(Tri));
+    g->Build();
+    return g;
+}
+void ref_grid_info(void* h, int32_t res[3], float cell[3], float lo[3], float hi[3], uint32_t* refs)
+{
+    Grid* g = (Grid*)h;
+    res[0] = g->resolution.x; res[1] = g->resolution.y; res[2] = g->resolution.z; cell[0] = g->cellSize.x; cell[1] = g->cellSize.y; cell[2] = g->cellSize.z;
+    for (int k = 0; k < 3; k++) { lo[k] = g->localBounds.bmin[k]; hi[k] = g->localBounds.bmax[k]; }
+    uint32_t r = 0; for (const GridCell& c : g->gridCells) r += (uint32_t)c.triIndices.size(); *refs = r;
+}
+void ref_grid_dump(void* h, uint32_t* cellStart /* cells + 1 */, int32_t* refs)
+{
+    Grid* g = (Grid*)h; uint32_t r = 0, i = 0;
+    for (const GridCell& c : g->gridCells) { cellStart[i++] = r; for (int t : c.triIndices) refs[r++] = t; }
+    cellStart[i] = r;
+}
+void ref_grid_intersect(void* h, const float* O, const float* D, uint32_t n, ref_hit* out)
+{
+    Grid* g = (Grid*)h;
+    for (uint32_t i = 0; i < n; i++) {
+        Ray r(float3(O[3 * i], O[3 * i + 1], O[3 * i + 2]), float3(D[3 * i], D[3 * i + 1], D[3 * i + 2]));
+        g->Intersect(r);
+        out[i].t = r.t; out[i].u = r.barycentric.x; out[i].v = r.barycentric.y;
+        out[i].objIdx = r.objIdx; out[i].triIdx = r.triIdx; out[i].traversed = r.traversed; out[i].tested = r.tested;
+    }
+}
+void ref_grid_free(void* h) { delete (Grid*)h; }
 
 /* tinyobj: corners resolved exactly as infra/model.cpp:16-54 does (missing normal/uv index -> zeros) */
 struct ref_obj { std::vector<float> pos, nrm, uv; };

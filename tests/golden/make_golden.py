@@ -108,6 +108,27 @@ def main():
                               tga=crc(ref.texture_load(os.path.join(RA, "textures/Stylized_Wood_basecolor.tga"))),
                               jpg=crc(ref.texture_load(os.path.join(RA, "textures/Wood_Tower_Col.jpg"))))
     np.save(os.path.join(HERE, "ref_texture_uv.npy"), uv)
+    # --- ref_alt: FileScene's alternative accelerators, built and traversed by the REAL infra/kdtree.cpp and infra/grid.cpp (oracle/_ref) --------------
+    # same triangles and the same rays as ref_bvh / ref_bvh_rays: structure CRCs + the reference's hits (t, u, v, triIdx, traversed, tested)
+    out["ref_alt"] = {}
+    alt = {}
+    zr = np.load(os.path.join(HERE, "ref_bvh_rays.npz"))
+    for m in ("bunny", "teapot", "cube"):
+        tris = simple_scene(m).bvh(0)["tris"]
+        out["ref_alt"][m] = {}
+        for kind in ("kd", "grid"):
+            a = ref.alt_accel(kind, tris)
+            d = a.dump()
+            hh = a.intersect(zr[m + "_O"], zr[m + "_D"])
+            a.close()
+            if kind == "kd":
+                out["ref_alt"][m][kind] = dict(nodes=crc(d["nodes"]), refs=crc(d["refs"]), nodeCount=int(len(d["nodes"])), refCount=int(len(d["refs"])), maxDepth=d["maxDepth"], nodesUsed=d["nodesUsed"])
+            else:
+                out["ref_alt"][m][kind] = dict(resolution=[int(x) for x in d["resolution"]], cellSize=crc(d["cellSize"]), boundsMin=crc(d["boundsMin"]), boundsMax=crc(d["boundsMax"]),
+                                               cellStart=crc(d["cellStart"]), refs=crc(d["refs"]), refCount=int(len(d["refs"])))
+            for f in ("t", "u", "v", "objIdx", "triIdx", "traversed", "tested"):
+                alt["%s_%s_%s" % (m, kind, f)] = hh[f]
+    np.savez_compressed(os.path.join(HERE, "ref_alt_rays.npz"), **alt)
     # --- ref_math: the reference's inline tmplmath.h functions on the path + infra/helper.h's Vertex table ------------------------------
     # math_probe input row = a[3], b[3], angles[3] (radians), s[3]; output row (120 floats) = normalize(a)[3], reflect(a, b)[3], cross(a, b)[3], dot(a, b),
     # mat4::Translate(a), RotateX(angles.x), RotateY(angles.y), RotateZ(angles.z), Scale(s) [16 each], FastInvertedTransformNoScale(RotateY(angles.y) with

@@ -379,3 +379,60 @@ def test_sky_lookup_deviation_from_libm_is_bounded(orc):
     assert flips <= n * 5e-4, flips                                           # measured: 11 of 200 000 directions (1 in 18 000) at this resolution
     assert np.abs(phi_det.astype(np.float64) - phi_lm).max() <= 6e-7 and np.abs(th_det.astype(np.float64) - th_lm).max() <= 6e-7   # <= 2.5 ulp at pi
     print("sky texel flips vs libm: %d of %d (%.4f %%)" % (flips, n, 100.0 * flips / n))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# FileScene's alternative accelerators: KDTree (infra/kdtree.cpp) and Grid (infra/grid.cpp), pinned to the real reference
+# (both files compile unmodified in oracle/_ref): structure CRCs in golden.json "ref_alt", the reference's own hits in ref_alt_rays.npz
+# ---------------------------------------------------------------------------------------------------------------
+def _alt_matches(d, g, kind):
+    if kind == "kd":
+        return (crc(d["nodes"]), crc(d["refs"]), len(d["nodes"]), len(d["refs"]), d["maxDepth"], d["nodesUsed"]) == (g["nodes"], g["refs"], g["nodeCount"], g["refCount"], g["maxDepth"], g["nodesUsed"])
+    return ([int(x) for x in d["resolution"]], crc(d["cellSize"]), crc(d["boundsMin"]), crc(d["boundsMax"]), crc(d["cellStart"]), crc(d["refs"])) == \
+           (g["resolution"], g["cellSize"], g["boundsMin"], g["boundsMax"], g["cellStart"], g["refs"])
+
+
+@pytest.mark.parametrize("kind", ["kd", "grid"])
+@pytest.mark.parametrize("mesh", ["bunny", "teapot", "cube"])
+def test_oracle_alt_accel_matches_reference_golden(orc, mesh, kind):
+    tris = simple_scene(orc, mesh).bvh(0)["tris"]
+    a = orc.alt_accel(kind, tris)
+    assert _alt_matches(a.dump(), G["ref_alt"][mesh][kind], kind)
+    z = np.load(os.path.join(GOLDEN, "ref_bvh_rays.npz")); r = np.load(os.path.join(GOLDEN, "ref_alt_rays.npz"))
+    h = a.intersect(z[mesh + "_O"], z[mesh + "_D"])
+    a.close()
+    for f in ("t", "u", "v"):
+        assert np.array_equal(h[f].view(np.uint32), r["%s_%s_%s" % (mesh, kind, f)].view(np.uint32)), f
+    for f in ("objIdx", "triIdx", "traversed", "tested"):
+        assert np.array_equal(h[f], r["%s_%s_%s" % (mesh, kind, f)]), f
+
+
+@pytest.mark.parametrize("kind,code", [("kd", 1), ("grid", 2)])
+@pytest.mark.parametrize("mesh", ["bunny", "cube"])
+def test_host_front_alt_accel_build_matches_reference_golden(tmp_path, mesh, kind, code):
+    from conftest import load_crt
+    from test_gpu_golden_and_edges import write_scene as write_simple_scene
+    crt = load_crt()
+    hs = crt.HostScene(write_simple_scene(tmp_path, mesh), 0, ASSETS)
+    assert _alt_matches(hs.build_alt(code), G["ref_alt"][mesh][kind], kind)
+
+
+def test_alt_accel_live(orc):
+    """authoring container only: oracle vs the real kdtree.cpp / grid.cpp on a mesh and rays the goldens do not cover"""
+    try:
+        ref = orc.Ref()
+    except FileNotFoundError:
+        pytest.skip("oracle/_ref is built only where /root/reference is mounted")
+    tris = simple_scene(orc, "log_fence").bvh(0)["tris"]
+    rng = np.random.default_rng(9)
+    O = rng.uniform(-3, 3, (2000, 3)).astype(np.float32); O[:, 1] = np.abs(O[:, 1]) + 0.1
+    D = (np.array([0, -0.5, 2], np.float32) + rng.uniform(-1, 1, (2000, 3)).astype(np.float32)) - O
+    D = (D / np.linalg.norm(D, axis=1, keepdims=True)).astype(np.float32)
+    D[:20, 0] = 0; D[20:40, 1] = 0; D[40:60, 2] = 0                   # axis-parallel components: infinite reciprocal, NaN plane distances
+    for kind in ("kd", "grid"):
+        a, b = ref.alt_accel(kind, tris), orc.alt_accel(kind, tris)
+        da, db = a.dump(), b.dump()
+        assert all(np.array_equal(da[k], db[k]) if isinstance(da[k], np.ndarray) else da[k] == db[k] for k in da)
+        ha, hb = a.intersect(O, D), b.intersect(O, D)
+        assert all(np.array_equal(ha[f].view(np.uint32), hb[f].view(np.uint32)) for f in ha.dtype.names), kind
+        a.close(); b.close()
