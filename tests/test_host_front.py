@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(crt):
     for sym in declared:
         assert hasattr(lib, sym), "include/*.h declares %s but libcrt_amd.so does not export it" % sym
     assert set(crt.ABI_SYMBOLS + crt.HOST_SYMBOLS) == set(declared)
-    assert lib.crt_abi_version() == 1
+    assert lib.crt_abi_version() == 2
 
 
 def test_record_layouts(crt):
