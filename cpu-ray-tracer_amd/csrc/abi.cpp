@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t, hipStream_t);
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
 extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
@@ -44,7 +44,7 @@ namespace {
 
 thread_local std::string g_createError;
 
-struct EventPair { hipEvent_t a, b; };
+struct EventPair { hipEvent_t a, b; int mode = -1; bool seen = false; };   // mode: latency-mode tag of a single-window launch (0 wide, 1 narrow), -1 otherwise
 
 } // namespace
 
@@ -83,6 +83,10 @@ struct crt_ctx {
     hipEvent_t sceneReady = nullptr;      // recorded behind the last in-place scene update; render launches wait for it on their stream
     crt::AltAccelDev alt{}; bool haveKd = false, haveGrid = false; std::vector<void*> altAllocs[2]; void* altTris = nullptr; uint32_t altTriCount = 0;   // KD-tree [0] / grid [1] buffers
     void* dQueryRays = nullptr; void* dQueryHits = nullptr; size_t queryCap = 0;      // crt_find_nearest staging (rays)
+    // ... chosen by measurement: the first single-window launch after a scene / camera change runs wide, the second narrow, later ones whichever was faster
+    // (HIP event durations of the launches themselves; identical pixels either way)
+    double tuneMs[2] = {0, 0}; int tuneCount[2] = {0, 0};
+    uint32_t narrowTiles = 0, narrowLanes = 8;   // latency mode of single-window launches: the first narrowTiles tiles of the dispatch order (inside the meshes' screen rectangle) run as 64 / narrowLanes narrow wavefronts
     uint32_t poolMinFrames = 65;  // launches of fewer frames (one stream per lane) run render_tiles_kernel
     bool usePool = true;          // render_pool_kernel (stream pool); CRT_RENDER_KERNEL=tiles selects render_tiles_kernel (one stream per lane)
     uint32_t ldsBytes = 0;
@@ -666,9 +670,9 @@ int crt_set_camera(crt_ctx* c, const float camPos[3], const float tl[3], const f
     return CRT_OK;      // the Scene block travels by value in every launch's kernel arguments
 }
 
-// Tiles (local indices 0..tileCount) ordered so that those inside the screen-space bounding rectangle of the meshes' world
-// box come first.  Pure scheduling heuristic: the projection uses the pin-hole camera of crt_set_camera in double precision
-// and is conservative on failure (a corner behind the eye makes every tile a candidate).
+// Tiles (local indices 0..tileCount) ordered so that those inside the screen-space bounding rectangle of the meshes' world box come first
+// (they are also the `narrowTiles` set of the latency mode).  Pure scheduling heuristic: the projection uses the pin-hole camera of crt_set_camera in double precision and is conservative on failure
+// (a corner behind the eye makes every tile a candidate).
 static int update_tile_order(crt_ctx* c)
 {
     if (!c->orderDirty || c->tileCount == 0) return 0;
@@ -679,28 +683,40 @@ static int update_tile_order(crt_ctx* c)
     const double rr = R[0] * R[0] + R[1] * R[1] + R[2] * R[2], dd = Dn[0] * Dn[0] + Dn[1] * Dn[1] + Dn[2] * Dn[2];
     double E[3]; for (int k = 0; k < 3; k++) E[k] = (double)s.topLeft[k] - s.camPos[k];
     const double num = E[0] * N[0] + E[1] * N[1] + E[2] * N[2];
-    double u0 = 1e30, u1 = -1e30, v0 = 1e30, v1 = -1e30; bool all = false;
-    for (int i = 0; i < 8 && !all; i++) {
-        double P[3] = {(i & 1) ? c->meshHi[0] : c->meshLo[0], (i & 2) ? c->meshHi[1] : c->meshLo[1], (i & 4) ? c->meshHi[2] : c->meshLo[2]};
-        double d[3] = {P[0] - s.camPos[0], P[1] - s.camPos[1], P[2] - s.camPos[2]};
-        const double den = d[0] * N[0] + d[1] * N[1] + d[2] * N[2];
-        const double t = den != 0 ? num / den : -1;
-        if (!(t > 0) || rr == 0 || dd == 0) { all = true; break; }
-        double Q[3]; for (int k = 0; k < 3; k++) Q[k] = s.camPos[k] + t * d[k] - s.topLeft[k];
-        const double u = (Q[0] * R[0] + Q[1] * R[1] + Q[2] * R[2]) / rr, v = (Q[0] * Dn[0] + Q[1] * Dn[1] + Q[2] * Dn[2]) / dd;
-        if (u < u0) u0 = u; if (u > u1) u1 = u; if (v < v0) v0 = v; if (v > v1) v1 = v;
-    }
-    int tx0 = 0, tx1 = c->tilesX - 1, ty0 = 0, ty1 = c->tilesY - 1;
-    if (!all) {
-        tx0 = (int)floor(u0 * c->cfg.width / 16.0) - 1; tx1 = (int)floor(u1 * c->cfg.width / 16.0) + 1;
-        ty0 = (int)floor(v0 * c->cfg.height / 16.0) - 1; ty1 = (int)floor(v1 * c->cfg.height / 16.0) + 1;
-    }
-    std::vector<uint32_t> first, rest;
+    // screen rectangle (in tiles, one tile of margin) of 8 world-space corners; false when a corner is behind the eye
+    auto rect_of = [&](const float* P8, int r[4]) -> bool {
+        double u0 = 1e30, u1 = -1e30, v0 = 1e30, v1 = -1e30;
+        for (int i = 0; i < 8; i++) {
+            const float* P = P8 + 3 * i;
+            double d[3] = {P[0] - s.camPos[0], P[1] - s.camPos[1], P[2] - s.camPos[2]};
+            const double den = d[0] * N[0] + d[1] * N[1] + d[2] * N[2];
+            const double t = den != 0 ? num / den : -1;
+            if (!(t > 0) || rr == 0 || dd == 0) return false;
+            double Q[3]; for (int k = 0; k < 3; k++) Q[k] = s.camPos[k] + t * d[k] - s.topLeft[k];
+            const double u = (Q[0] * R[0] + Q[1] * R[1] + Q[2] * R[2]) / rr, v = (Q[0] * Dn[0] + Q[1] * Dn[1] + Q[2] * Dn[2]) / dd;
+            if (u < u0) u0 = u; if (u > u1) u1 = u; if (v < v0) v0 = v; if (v > v1) v1 = v;
+        }
+        r[0] = (int)floor(u0 * c->cfg.width / 16.0) - 1; r[1] = (int)floor(u1 * c->cfg.width / 16.0) + 1;
+        r[2] = (int)floor(v0 * c->cfg.height / 16.0) - 1; r[3] = (int)floor(v1 * c->cfg.height / 16.0) + 1;
+        return true;
+    };
+    float world[24];
+    for (int i = 0; i < 8; i++) { world[3 * i] = (i & 1) ? c->meshHi[0] : c->meshLo[0]; world[3 * i + 1] = (i & 2) ? c->meshHi[1] : c->meshLo[1]; world[3 * i + 2] = (i & 4) ? c->meshHi[2] : c->meshLo[2]; }
+    int wr[4] = {0, c->tilesX - 1, 0, c->tilesY - 1};
+    const bool all = !rect_of(world, wr);
+    std::vector<uint32_t> first, second, rest;
     for (uint32_t i = 0; i < c->tileCount; i++) {
         const uint32_t tile = c->tileFirst + i * c->tileStride;
         const int tx = (int)(tile % (uint32_t)c->tilesX), ty = (int)(tile / (uint32_t)c->tilesX);
-        ((tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) ? first : rest).push_back(i);
+        const bool inRect = tx >= wr[0] && tx <= wr[1] && ty >= wr[2] && ty <= wr[3];
+        if (inRect) first.push_back(i); else rest.push_back(i);
     }
+    // latency mode (single-window launches): the tiles of the rectangle MAY run as narrow wavefronts; whether that pays depends on the scene — measured
+    // (tools/latency_probe.py, one 64-spp render, 8 lanes): bunny 1280x720 32.6 -> 27.7 ms (16 lanes 30.3, 4 lanes 34.8; every tile narrow 40.0), TLAS scene
+    // 58.7 -> 51.2 ms, watch-tower 1920x1080 79.8 -> 109.7 ms — so crt_render decides by timing both on the first two launches (see tuneMs)
+    c->narrowTiles = all ? 0u : (uint32_t)first.size();
+    c->tuneCount[0] = c->tuneCount[1] = 0;
+    if (const char* e = getenv("CRT_NARROW_LANES")) { c->narrowLanes = (uint32_t)atoi(e); if (c->narrowLanes == 0u) c->narrowTiles = 0u; }
     first.insert(first.end(), rest.begin(), rest.end());
     // No host synchronisation: the copy runs on the main stream, which is ordered behind every render launch submitted so far (it waits for
     // each launch's end event before that launch's accumulate), so the previous order is no longer read when it is overwritten; later
@@ -726,6 +742,18 @@ static size_t window_bytes(const crt_ctx* c, uint32_t passes) { return sample_by
 
 // Timing pairs of launches that have completed are folded into running totals and recycled, so a host that renders forever and never
 // asks for the timing (an interactive Tick loop) keeps a bounded number of HIP events alive.
+// latency-mode auto-tuning: durations of completed single-window launches, by mode (each launch is looked at once)
+static void harvest_tuning(crt_ctx* c)
+{
+    for (auto& ev : c->evRender) {
+        if (ev.mode < 0 || ev.seen) continue;
+        if (hipEventQuery(ev.b) != hipSuccess) break;                   // launches complete in order per stream; stop at the first unfinished one
+        float t = 0;
+        if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) { c->tuneMs[ev.mode] = c->tuneCount[ev.mode] ? (c->tuneMs[ev.mode] < t ? c->tuneMs[ev.mode] : t) : t; c->tuneCount[ev.mode]++; }
+        ev.seen = true;
+    }
+}
+
 static void fold_completed(crt_ctx* c, std::deque<EventPair>& list, double* ms, uint32_t* count)
 {
     while (list.size() > 64 && hipEventQuery(list.front().b) == hipSuccess) {
@@ -742,6 +770,7 @@ static int take_event(crt_ctx* c, std::deque<EventPair>& list, EventPair* out)
     if (c->evPool.empty()) {
         HIPCK(c, hipEventCreate(&ev.a)); HIPCK(c, hipEventCreate(&ev.b));
     } else { ev = c->evPool.back(); c->evPool.pop_back(); }
+    ev.mode = -1; ev.seen = false;
     list.push_back(ev); *out = ev;
     return 0;
 }
@@ -850,8 +879,17 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         if (c->sceneReady) HIPCK(c, hipStreamWaitEvent(st, c->sceneReady, 0));
         void* slab = c->pool + off;
         EventPair ev;
+        harvest_tuning(c);
         fold_completed(c, c->evRender, &c->foldedRenderMs, &c->foldedLaunches); fold_completed(c, c->evAcc, &c->foldedAccMs, nullptr);
         if ((r = take_event(c, c->evRender, &ev))) return r;
+        // latency mode of a single-window launch (render_tiles_kernel): wide, or narrow wavefronts for the tiles of the meshes' rectangle
+        uint32_t narrow = 0;
+        if (nf <= 64u && nf > c->narrowLanes && c->narrowTiles != 0u && !c->cfg.collectStats) {
+            int mode = c->tuneCount[0] == 0 ? 0 : (c->tuneCount[1] == 0 ? 1 : (c->tuneMs[1] < c->tuneMs[0] ? 1 : 0));
+            if (const char* e = getenv("CRT_NARROW_FORCE")) mode = atoi(e) ? 1 : 0;
+            narrow = mode ? c->narrowTiles : 0u;
+            c->evRender.back().mode = mode;
+        }
         HIPCK(c, hipEventRecord(ev.a, st));
         // the stream pool needs more streams than lanes to pay off: launches of <= 64 frames (one stream per lane) run render_tiles_kernel
         if (c->usePool && c->hScene.ref16ok && nf >= c->poolMinFrames)
@@ -859,7 +897,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
                                             c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->cfg.collectStats, st));
         else
             HIPCK(c, crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, st));
+                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, narrow, c->narrowLanes, st));
         HIPCK(c, hipEventRecord(ev.b, st));
         // ordered accumulation on the main stream (frame order = launch order), behind this launch
         HIPCK(c, hipStreamWaitEvent(c->stream, ev.b, 0));

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                                                            Counters* __restrict__ counters, unsigned long long* __restrict__ tileClocks,
                                                            const uint32_t* __restrict__ tileOrder,
                                                            uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
-                                                           uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t windows)
+                                                           uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t windows,
+                                                           uint32_t narrowTiles, uint32_t narrowLanes)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -80,11 +81,21 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     // all windows of the expensive tiles are dispatched first and the cheap tiles fill the machine behind them, so a long job is
     // one grid whose duration is total work / machine throughput instead of a sequence of launches that each end on their
     // heaviest tile.
-    const uint32_t rank = blockIdx.x / windows, win = blockIdx.x - rank * windows;
+    // Latency mode (a launch of ONE window, narrowTiles > 0): the launch ends on its most expensive tile — one serial stream per lane, and every
+    // trip of that wave pays for all the phases its 64 lanes populate.  The first `narrowTiles` tiles of the order (those that can see the meshes)
+    // are therefore rendered by 64 / narrowLanes wavefronts of narrowLanes lanes each: fewer phases are populated per trip, so each stream's
+    // serial chain advances faster, and the idle part of the chip takes the extra wavefronts.  laneBase = first frame of this wavefront.
+    uint32_t rank, win = 0u, laneBase = 0u;
+    if (narrowTiles != 0u) {
+        const uint32_t subs = 64u / narrowLanes, nb = narrowTiles * subs;
+        if (blockIdx.x < nb) { rank = blockIdx.x / subs; laneBase = (blockIdx.x - rank * subs) * narrowLanes; }
+        else rank = narrowTiles + (blockIdx.x - nb);
+    } else { rank = blockIdx.x / windows; win = blockIdx.x - rank * windows; }
     if (rank >= tileCount) return;
     const uint32_t tl = tileOrder ? tileOrder[rank] : rank;
     sppFirst += win * 64u * passes;
     frames = (frames - win * 64u < 64u) ? frames - win * 64u : 64u;               // frames of THIS window (the last one may be partial)
+    if (narrowTiles != 0u && blockIdx.x < narrowTiles * (64u / narrowLanes)) frames = frames > laneBase ? ((frames - laneBase < narrowLanes) ? frames - laneBase : narrowLanes) : 0u;
     slab += (size_t)win * ((size_t)tileCount * 256u * 64u * passes);              // this window's region of the sample slab
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
@@ -93,7 +104,8 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 
     Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
     uint32_t trips = 0;
-    const int shadeBatch = windows >= 8u ? CRT_SHADE_BATCH_JOB : CRT_SHADE_BATCH;
+    const bool narrowWave = narrowTiles != 0u && blockIdx.x < narrowTiles * (64u / narrowLanes);
+    const int shadeBatch = narrowWave ? (int)((narrowLanes * 3u + 7u) / 8u) : (windows >= 8u ? CRT_SHADE_BATCH_JOB : CRT_SHADE_BATCH);   // (24 of 64 lanes, scaled to a narrow wavefront)
 #ifdef CRT_STAMPS
     // diagnostic build (-DCRT_STAMPS): shader-clock time per phase of this wave; never compiled into the product
     unsigned long long stT[6] = {0, 0, 0, 0, 0, 0}; uint32_t stN[4] = {0, 0, 0, 0}; uint32_t stL[4] = {0, 0, 0, 0};
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 
     bool live = lane < frames;
     uint64_t liveMask = __builtin_amdgcn_ballot_w64(live);                    // lanes whose stream still has pixels to render
-    uint32_t seed = init_seed(tx + ty * (uint32_t)sc.W + (sppFirst + lane * passes) * 1799u);   // renderer.cpp:120
+    uint32_t seed = init_seed(tx + ty * (uint32_t)sc.W + (sppFirst + (laneBase + lane) * passes) * 1799u);   // renderer.cpp:120
     uint32_t item = 0;
     // world-space ray of the current path segment, its nearest hit so far, path state
     f3 O = camPos, D = camPos, rD = camPos; bool inside = false; int depth = 0;
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 #endif
                 uint32_t pix = item, pass = 0;
                 if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
-                slab[((size_t)tl * 256u + pix) * (64u * passes) + (lane * passes + pass)] = make_float4(L.x, L.y, L.z, 0.0f);
+                slab[((size_t)tl * 256u + pix) * (64u * passes) + ((laneBase + lane) * passes + pass)] = make_float4(L.x, L.y, L.z, 0.0f);
                 item++;
                 gen = true;
                 if (item >= items) { live = false; gen = false; }
@@ -798,13 +810,15 @@ __global__ __launch_bounds__(64) void resolve_kernel(const float4* __restrict__ 
 // ------------------------------------------------------------------------------------------------------------
 extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                         uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
-                                        uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, hipStream_t stream)
+                                        uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, uint32_t narrowTiles, uint32_t narrowLanes, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
     const uint32_t windows = (frames + 63u) / 64u;                      // one 64-lane wavefront per (tile, 64-frame window)
     if ((unsigned long long)tileCount * windows > 0x7fffffffull) return hipErrorInvalidValue;
-    dim3 grid(tileCount * windows), block(64);
-#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows)
+    if (windows != 1u || narrowLanes == 0u || narrowLanes >= 64u || (64u % narrowLanes) != 0u || frames <= narrowLanes || collectStats) narrowTiles = 0u;   // latency mode: single-window launches of more frames than one narrow wavefront holds
+    if (narrowTiles > tileCount) narrowTiles = tileCount;
+    dim3 grid(narrowTiles ? narrowTiles * (64u / narrowLanes) + (tileCount - narrowTiles) : tileCount * windows), block(64);
+#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows, narrowTiles, narrowLanes)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH(0, true); else CRT_LAUNCH(0, false); }
     else { if (collectStats) CRT_LAUNCH(1, true); else CRT_LAUNCH(1, false); }
 #undef CRT_LAUNCH
