@@ -217,11 +217,15 @@ def main():
     # Dominant kernel = render_tiles_kernel.  Every launch of it in this process (the warm-up job and the timed job) enters the
     # average, so that avg_launch_ms is the figure rocprofv3 --kernel-trace --stats reports for the same command; bytes = SURVEY 8(d)'s
     # per-ray / per-sample figures x the device counters of one step x the steps a launch covers.
-    all_launches = launches + tm_warm["render_launches"]
-    all_ms = kernel_ms + tm_warm["render_kernel_ms"]
+    # (the back end picks render_pool_kernel for launches many times larger than the machine and render_tiles_kernel below that: the warm-up job
+    # enters the average only when it ran the same kernel as the timed job)
+    job_kernel = "render_pool_kernel" if tm.get("pool_launches", 0) == launches and launches > 0 else "render_tiles_kernel"
+    warm_same = (tm_warm.get("pool_launches", 0) == tm_warm["render_launches"]) == (job_kernel == "render_pool_kernel")
+    all_launches = launches + (tm_warm["render_launches"] if warm_same else 0)
+    all_ms = kernel_ms + (tm_warm["render_kernel_ms"] if warm_same else 0.0)
     avg_launch_ms = all_ms / max(all_launches, 1)
     launches_per_step = launches / args.steps
-    alg_bytes_launch = algorithmic_bytes(counts) * (args.steps + args.warmup) / max(all_launches, 1)
+    alg_bytes_launch = algorithmic_bytes(counts) * (args.steps + (args.warmup if warm_same else 0)) / max(all_launches, 1)
     achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     job_launch_ms = kernel_ms / max(launches, 1)
     # HBM bytes and VALU wave-instructions of the render kernel from the PMC passes (tools/collect_profiles.sh -> profiles/hbm_traffic.json),
@@ -232,7 +236,7 @@ def main():
     if os.path.exists(pmc_path):
         try:
             t = json.load(open(pmc_path))
-            if t.get("workload") == [args.scene, args.kind, W, H, SPP] and world == 1:
+            if t.get("workload") == [args.scene, args.kind, W, H, SPP] and world == 1 and job_kernel in t.get("kernel", ""):
                 pmc = t
                 pw = t["per_window"]
                 traffic = int((pw["fetch_bytes_raw"] + pw["write_bytes"]) * windows_per_launch)
@@ -265,7 +269,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "hbm_actual_frac": None if not traffic or job_launch_ms <= 0 else round(traffic / (job_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "limiter": "valu_issue (fp32 instruction issue on divergent code; the algorithmic bytes are served by L2: see hbm_actual_frac and valu_issue)",
-                     "kernel": "render_pool_kernel" if launches_per_step and windows_per_launch > 1 else "render_tiles_kernel", "avg_launch_ms": round(avg_launch_ms, 4), "launches": all_launches,
+                     "kernel": job_kernel, "avg_launch_ms": round(avg_launch_ms, 4), "launches": all_launches,
                      "algorithmic_bytes_per_launch": int(alg_bytes_launch),
                      "job_launch_ms": round(job_launch_ms, 4), "job_launch_windows": round(1 / launches_per_step, 2) if launches_per_step else None,
                      "job_launch_achieved": round(algorithmic_bytes(counts) / max(launches_per_step, 1e-9) / (job_launch_ms * 1e-3) / 1e9, 2) if job_launch_ms > 0 else None,

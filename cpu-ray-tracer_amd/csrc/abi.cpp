@@ -87,13 +87,13 @@ struct crt_ctx {
     // (HIP event durations of the launches themselves; identical pixels either way)
     double tuneMs[2] = {0, 0}; int tuneCount[2] = {0, 0};
     uint32_t narrowTiles = 0, narrowLanes = 8;   // latency mode of single-window launches: the first narrowTiles tiles of the dispatch order (inside the meshes' screen rectangle) run as 64 / narrowLanes narrow wavefronts
-    uint32_t poolMinFrames = 65;  // launches of fewer frames (one stream per lane) run render_tiles_kernel
+    uint64_t poolMinWaves = 90000; // launches of fewer (tile, 64-frame window) pairs run render_tiles_kernel: see crt_render
     bool usePool = true;          // render_pool_kernel (stream pool); CRT_RENDER_KERNEL=tiles selects render_tiles_kernel (one stream per lane)
     uint32_t ldsBytes = 0;
     // timing of the last crt_render
     std::vector<EventPair> evPool; size_t evUsedRender = 0, evUsedAcc = 0;
     std::deque<EventPair> evRender, evAcc;                        // launches not yet folded into the totals below (oldest first)
-    double foldedRenderMs = 0, foldedAccMs = 0; uint32_t foldedLaunches = 0;
+    double foldedRenderMs = 0, foldedAccMs = 0; uint32_t foldedLaunches = 0, poolLaunches = 0;
 
     int fail(int code, const char* fmt, ...)
     {
@@ -190,7 +190,7 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     c->cfg = *cfg;
     if (const char* k = getenv("CRT_RENDER_KERNEL")) {             // tests / A-B runs: "tiles" = never the stream pool, "pool_always" = also for launches of <= 64 frames
         c->usePool = strcmp(k, "tiles") != 0;
-        if (!strcmp(k, "pool_always")) c->poolMinFrames = 1;
+        if (!strcmp(k, "pool_always")) c->poolMinWaves = 0;
     }
     if (c->cfg.depthLimit < 0) c->cfg.depthLimit = 5;
     if (c->cfg.depthLimit > 5) { g_createError = "crt_create: depthLimit > 5 unsupported (throughput stack holds 5 factors; reference default is 5)"; delete c; return CRT_ERR_UNSUPPORTED; }
@@ -891,8 +891,13 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
             c->evRender.back().mode = mode;
         }
         HIPCK(c, hipEventRecord(ev.a, st));
-        // the stream pool needs more streams than lanes to pay off: launches of <= 64 frames (one stream per lane) run render_tiles_kernel
-        if (c->usePool && c->hScene.ref16ok && nf >= c->poolMinFrames)
+        // Which render kernel: the stream pool executes a third fewer instructions per sample, but its wavefronts own 128 streams for 64 lanes, so the most
+        // expensive tiles take about twice as long per wavefront; a launch that is not many times larger than the machine (4 096 - 5 120 wavefronts in
+        // flight) ends on those and is faster with one stream per lane.  Measured cross-over (tools/crossover.py): bunny / TLAS scene 1280x720 at 20 - 26
+        // windows, watch-tower 1920x1080 at 7, i.e. 11 - 19 rounds of the machine.
+        const bool pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * ((nf + 63u) / 64u) >= c->poolMinWaves && (c->poolMinWaves == 0 || nf > 64u);
+        if (pool) c->poolLaunches++;
+        if (pool)
             HIPCK(c, crt_launch_render_pool(&c->hScene, slab, (char*)slab + (size_t)((nf + 63u) / 64u) * sample_bytes_per_window(c, passes), c->dCounters, c->dTileClocks, c->dTileOrder,
                                             c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->cfg.collectStats, st));
         else
@@ -1114,7 +1119,8 @@ int crt_get_timing(crt_ctx* c, crt_timing* out)
     for (auto& ev : c->evRender) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->render_kernel_ms += ms; }
     for (auto& ev : c->evAcc) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->resolve_kernel_ms += ms; }
     out->render_launches = (uint32_t)c->evRender.size() + c->foldedLaunches;
-    c->foldedRenderMs = c->foldedAccMs = 0; c->foldedLaunches = 0;
+    out->pool_launches = c->poolLaunches;
+    c->foldedRenderMs = c->foldedAccMs = 0; c->foldedLaunches = 0; c->poolLaunches = 0;
     for (auto& ev : c->evRender) c->evPool.push_back(ev);      // the figures cover every launch since the previous crt_get_timing
     for (auto& ev : c->evAcc) c->evPool.push_back(ev);
     c->evRender.clear(); c->evAcc.clear();

@@ -319,16 +319,23 @@ __device__ __forceinline__ void find_nearest_seq(const Scene& sc, f3 O, f3 D, f3
     if (h.objIdx >= 2) cn.meshhits++;
 }
 
-// Texture::Sample, template/texture.h:61-96
-__device__ __forceinline__ f3 tex_sample(const Scene& sc, uint32_t offset, int w, int hgt, float u, float v)
+// Texture::Sample, template/texture.h:61-96, in its two halves: nearest-texel index in the pooled texel array, and 0x00RRGGBB -> float3
+__device__ __forceinline__ uint32_t tex_index(uint32_t offset, int w, int hgt, float u, float v)
 {
     u = clamp_tm(u, 0.0f, 1.0f);
     v = 1 - clamp_tm(v, 0.0f, 1.0f);
     int x = (int)(u * w), y = (int)(v * hgt);
     x = clampi(x, 0, w - 1); y = clampi(y, 0, hgt - 1);
-    const uint32_t p = sc.texels[offset + (uint32_t)x + (uint32_t)y * (uint32_t)w];
+    return offset + (uint32_t)x + (uint32_t)y * (uint32_t)w;
+}
+__device__ __forceinline__ f3 tex_unpack(uint32_t p)
+{
     const float s = 1 / 255.0f;
     return mk3(((p >> 16) & 0xFF) * s, ((p >> 8) & 0xFF) * s, (p & 0xFF) * s);
+}
+__device__ __forceinline__ f3 tex_sample(const Scene& sc, uint32_t offset, int w, int hgt, float u, float v)
+{
+    return tex_unpack(sc.texels[tex_index(offset, w, hgt, u, v)]);
 }
 
 // GetSkyColor, infra/scene/file_scene.cpp:142-154

@@ -52,6 +52,13 @@ constexpr uint32_t kQueueMask = 127u;                            // queues are r
 #define CRT_POOL_STARVE 40        // ... unless fewer than this many streams are walking or ready to walk
 #endif
 
+#ifdef CRT_POOL_STAMPS
+// diagnostic build only (-DCRT_POOL_STAMPS): shader-clock time of the sections of the loop, summed over all waves into the (otherwise unused) counter
+// slots 2..6 of a non-counting launch: [2] walk incl. the wait for the records, [3] swap out / in + record loads, [4] END passes, [5] BOUNCE passes, [6] trips
+#define CRT_PSTAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define CRT_PSTAMP(var)
+#endif
 template <int KIND, bool COUNT, int S>
 __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
                                                              unsigned long long* __restrict__ tileClocks, const uint32_t* __restrict__ tileOrder,
@@ -154,7 +161,11 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
         rdyT += (uint32_t)__popcll(mW); endT += (uint32_t)__popcll(mE); bncT += (uint32_t)__popcll(mB);
     };
 
+#ifdef CRT_POOL_STAMPS
+    unsigned long long pst[5] = {0, 0, 0, 0, 0};
+#endif
     for (;;) {
+        CRT_PSTAMP(p0);
         // ---------------- D. walk: state ballots of the resident streams, then the phases that have lanes ------------------------------
         const bool isNode = res && (KIND == 1 ? (((cur >> 15) ^ (cur >> 14)) & 1u) != 0u : (cur & kRef16TagMask) == kRef16Interior);
         const bool isTri = res && cur != kRefDone && (cur & kRef16TagMask) == 0u;
@@ -226,6 +237,7 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
             if (COUNT && !more && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
             cur = next;
         }
+        CRT_PSTAMP(p1);
         asm volatile("" ::: "memory");
         // ---------------- A. swap out: streams whose walk is over park their hit and queue for shading ------------------------------
         {
@@ -290,6 +302,7 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
             if (!want) { oa = 0u; ob = 32u; }
             if (__builtin_amdgcn_ballot_w64(want) != 0ull) { q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, ob); q3 = ldg(geom, ob + 16u); }
         }
+        CRT_PSTAMP(p2);
         asm volatile("" ::: "memory");
         {
             // ---------------- B. shading passes (their latency-free arithmetic also covers the record loads just issued) --------------------
@@ -323,21 +336,20 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                         for (int j = 0; j < 3; j++) fk[3 * k + j] = __hip_atomic_load(fac + (3 * k + j) * S + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                f3 L = mk3(0, 0, 0);
-                if (miss) {                                                       // GetSkyColor, file_scene.cpp:142-154
+                // GetSkyColor (file_scene.cpp:142-154): the texel fetch is issued here and consumed after the next ray has been set up — the skydome is far
+                // larger than the caches, and the (long) latency of this one load is then covered by the arithmetic of ray generation and new_ray
+                uint32_t skyTexel = 0u;
+                if (miss) {
                     const float phi = crt_atan2f(-D.z, D.x) + CRT_PI, theta = crt_acosf(-D.y);
-                    L = tex_sample(sc, sc.skyOffset, sc.skyW, sc.skyH, phi * CRT_INV2PI, theta * CRT_INVPI);
-                } else if (ended) L = (depth >= sc.depthLimit) ? mk3(0, 0, 0) : mk3(24, 24, 22);   // depth limit -> 0; GetLightColor, file_scene.cpp:164-167
+                    skyTexel = sc.texels[tex_index(sc.skyOffset, sc.skyW, sc.skyH, phi * CRT_INV2PI, theta * CRT_INVPI)];
+                }
                 bool gen = act && first;
+                size_t sampleAt = 0;
                 if (ended) {
-                    // unwind the recursion (innermost factor first: albedo*medium*Sample(...) multiplies on return), store the sample
-#pragma unroll
-                    for (int k = 4; k >= 0; k--)
-                        if (depth > k) L = mk3(fk[3 * k], fk[3 * k + 1], fk[3 * k + 2]) * L;
                     uint32_t pix = item, pass = 0;
                     if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
                     const uint32_t fr = frame0 + s;                                // frame of the launch -> (64-frame window, sample row position)
-                    slab[(((size_t)(fr >> 6) * tileCount + tl) * 256u + pix) * rowLen + ((fr & 63u) * passes + pass)] = make_float4(L.x, L.y, L.z, 0.0f);
+                    sampleAt = (((size_t)(fr >> 6) * tileCount + tl) * 256u + pix) * rowLen + ((fr & 63u) * passes + pass);
                     item++;
                     gen = item < items;                                            // else: the stream has rendered its 256 pixels
                 }
@@ -353,7 +365,20 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                     cn.primary++;
                 }
                 new_ray(gen, s, v, true, camPos, seed, item);                      // depth 0, outside, not fresh
+                if (ended) {
+                    // the finished path's radiance: sky colour / light (24,24,22) / 0 at the depth limit (renderer.cpp:54-55, 69; GetLightColor file_scene.cpp:164-167), times the
+                    // throughput factors in recursion order (innermost first: albedo*medium*Sample(...) multiplies on return)
+                    f3 L = miss ? tex_unpack(skyTexel) : ((depth >= sc.depthLimit) ? mk3(0, 0, 0) : mk3(24, 24, 22));
+#pragma unroll
+                    for (int k = 4; k >= 0; k--)
+                        if (depth > k) L = mk3(fk[3 * k], fk[3 * k + 1], fk[3 * k + 2]) * L;
+                    slab[sampleAt] = make_float4(L.x, L.y, L.z, 0.0f);
+                }
             }
+            CRT_PSTAMP(p3);
+#ifdef CRT_POOL_STAMPS
+            pst[2] += p3 - p2;
+#endif
             asm volatile("" ::: "memory");
             if (runBnc) {
                 // ---------------- B2. BOUNCE pass: surface hit (floor or mesh) below the depth limit (renderer.cpp:56-99) ----------------
@@ -460,8 +485,14 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                 }
                 new_ray(act, s, v, false, O, seed, item | ((uint32_t)(depth + 1) << kMetaDepthShift) | (newInside ? kMetaInside : 0u));
             }
+#ifdef CRT_POOL_STAMPS
+            { CRT_PSTAMP(p4); pst[0] += p1 - p0; pst[1] += p2 - p1; pst[3] += p4 - p3; pst[4]++; }
+#endif
         }
     }
+#ifdef CRT_POOL_STAMPS
+    if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&counters->v[2 + i], pst[i]);
+#endif
 #undef CRT_TOP
 
     if (COUNT && tileClocks && lane == 0 && groups == 1u) {                     // instrumentation: per-tile wall time + loop trips (one group per tile only)

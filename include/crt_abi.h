@@ -130,7 +130,7 @@ typedef struct crt_timing {                /* covers every launch since the prev
                                  different render streams overlap, so this sum can exceed wall time)                 */
     float resolve_kernel_ms;  /* Σ duration of the ordered accumulate kernels                                        */
     uint32_t render_launches; /* number of path-tracing kernel launches                                              */
-    uint32_t reserved;
+    uint32_t pool_launches;   /* ... of which render_pool_kernel (stream pool; the others are render_tiles_kernel)   */
 } crt_timing;
 
 /* ---- life cycle ----------------------------------------------------------------------------------- */

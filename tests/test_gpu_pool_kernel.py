@@ -1,6 +1,6 @@
-"""render_pool_kernel (stream pool: more RNG streams than lanes per wavefront) against the oracle and against render_tiles_kernel, at
-launch sizes where the back end selects it by itself (> 64 frames per launch): partial groups of streams, passes > 1, two-level
-scenes, materials, statistics builds, tile ownership."""
+"""render_pool_kernel (stream pool: more RNG streams than lanes per wavefront) against the oracle and against render_tiles_kernel: partial groups
+of streams, passes > 1, two-level scenes, materials, statistics builds, tile ownership.  The back end selects the pool kernel by itself only for
+launches many times larger than the machine (crt_render); the small cases here force it (CRT_RENDER_KERNEL=pool_always), one full-size case does not."""
 import numpy as np
 import pytest
 
@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("xml,kind,W,H,frames,passes", [("bunny_scene.xml", 0, 64, 48, 130, 1), ("tlas_scene.xml", 1, 64, 48, 200, 2),
                                                          ("tower_scene.xml", 0, 48, 32, 97, 3), ("cube_scene.xml", 0, 32, 32, 300, 1)])
-def test_pool_kernel_matches_oracle(crt, orc, xml, kind, W, H, frames, passes):
+def test_pool_kernel_matches_oracle(crt, orc, monkeypatch, xml, kind, W, H, frames, passes):
+    monkeypatch.setenv("CRT_RENDER_KERNEL", "pool_always")
     hs = crt.HostScene(scene_path(xml), kind, ASSETS)
     ctx = crt.Context(W, H, collect_stats=True, max_frames_per_launch=4096)      # statistics build of the pool kernel: all counters
     hs.upload(ctx)
@@ -32,18 +33,28 @@ def test_pool_kernel_matches_oracle(crt, orc, xml, kind, W, H, frames, passes):
 def test_pool_and_tiles_kernels_are_bit_identical(crt, monkeypatch, xml, kind, W, H, frames):
     hs = crt.HostScene(scene_path(xml), kind, ASSETS)
     out = {}
-    for k in ("tiles", "pool"):
+    for k in ("tiles", "pool_always"):
         monkeypatch.setenv("CRT_RENDER_KERNEL", k)
         ctx = crt.Context(W, H)
         hs.upload(ctx)
         ctx.render(1, frames, 1)
         out[k] = (ctx.accumulator(), ctx.counters()["rays"])
         ctx.close()
-    assert np.array_equal(out["pool"][0], out["tiles"][0]) and out["pool"][1] == out["tiles"][1]
+    assert np.array_equal(out["pool_always"][0], out["tiles"][0]) and out["pool_always"][1] == out["tiles"][1]
 
 
-def test_pool_kernel_tile_ownership_and_frame_batches(crt, orc):
+def test_large_job_selects_the_pool_kernel_and_matches_the_tiles_kernel(crt, monkeypatch):
+    """1280x720 x 26 windows = 93 600 (tile, window) pairs: the default choice is the stream pool; same bits as one stream per lane"""
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(1280, 720); hs.upload(ctx); ctx.render(1, 26 * 64, 1); a = ctx.accumulator(); ra = ctx.counters()["rays"]; ctx.close()
+    monkeypatch.setenv("CRT_RENDER_KERNEL", "tiles")
+    ctx = crt.Context(1280, 720); hs.upload(ctx); ctx.render(1, 26 * 64, 1); b = ctx.accumulator(); rb = ctx.counters()["rays"]; ctx.close()
+    assert np.array_equal(a, b) and ra == rb
+
+
+def test_pool_kernel_tile_ownership_and_frame_batches(crt, orc, monkeypatch):
     """two interleaved tile owners, launches of 96 frames (a partial group of streams each), summed == one context == oracle"""
+    monkeypatch.setenv("CRT_RENDER_KERNEL", "pool_always")
     W, H, frames = 96, 64, 200
     hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
     tiles = (W // 16) * (H // 16)
@@ -63,6 +74,7 @@ def test_pool_kernel_tile_ownership_and_frame_batches(crt, orc):
 
 def test_scene_too_large_for_16_bit_references_falls_back(crt, monkeypatch):
     """render_pool_kernel walks 16-bit node references; a scene that does not fit (here: forced) renders with render_tiles_kernel, same bits"""
+    monkeypatch.setenv("CRT_RENDER_KERNEL", "pool_always")
     hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
     ctx = crt.Context(64, 48); hs.upload(ctx); ctx.render(1, 100, 1); a = ctx.accumulator(); ctx.close()
     monkeypatch.setenv("CRT_DEBUG_NO_REF16", "1")
