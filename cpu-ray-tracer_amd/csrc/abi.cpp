@@ -87,7 +87,7 @@ struct crt_ctx {
     // (HIP event durations of the launches themselves; identical pixels either way)
     double tuneMs[2] = {0, 0}; int tuneCount[2] = {0, 0};
     uint32_t narrowTiles = 0, narrowLanes = 8;   // latency mode of single-window launches: the first narrowTiles tiles of the dispatch order (inside the meshes' screen rectangle) run as 64 / narrowLanes narrow wavefronts
-    uint64_t poolMinWaves = 90000; // launches of fewer (tile, 64-frame window) pairs run render_tiles_kernel: see crt_render
+    uint64_t poolMinWaves = 65000; // launches of fewer (tile, 64-frame window) pairs run render_tiles_kernel: see crt_render
     bool usePool = true;          // render_pool_kernel (stream pool); CRT_RENDER_KERNEL=tiles selects render_tiles_kernel (one stream per lane)
     uint32_t ldsBytes = 0;
     // timing of the last crt_render
@@ -893,8 +893,9 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         HIPCK(c, hipEventRecord(ev.a, st));
         // Which render kernel: the stream pool executes a third fewer instructions per sample, but its wavefronts own 128 streams for 64 lanes, so the most
         // expensive tiles take about twice as long per wavefront; a launch that is not many times larger than the machine (4 096 - 5 120 wavefronts in
-        // flight) ends on those and is faster with one stream per lane.  Measured cross-over (tools/crossover.py): bunny / TLAS scene 1280x720 at 20 - 26
-        // windows, watch-tower 1920x1080 at 7, i.e. 11 - 19 rounds of the machine.
+        // flight) ends on those and is faster with one stream per lane.  Measured cross-over (tools/crossover.py, bench.py --steps): bunny 1280x720 at 17 - 20
+        // windows (20 windows: 81.0 ms pool, 87.6 ms tiles), TLAS scene at ~28, watch-tower 1920x1080 at 7 — 56 000 ... 100 000 (tile, window) pairs; the
+        // threshold sits at the low end of that range.
         const bool pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * ((nf + 63u) / 64u) >= c->poolMinWaves && (c->poolMinWaves == 0 || nf > 64u);
         if (pool) c->poolLaunches++;
         if (pool)

@@ -44,11 +44,11 @@ def test_pool_and_tiles_kernels_are_bit_identical(crt, monkeypatch, xml, kind, W
 
 
 def test_large_job_selects_the_pool_kernel_and_matches_the_tiles_kernel(crt, monkeypatch):
-    """1280x720 x 26 windows = 93 600 (tile, window) pairs: the default choice is the stream pool; same bits as one stream per lane"""
+    """1280x720 x 20 windows = 72 000 (tile, window) pairs: the default choice is the stream pool; same bits as one stream per lane"""
     hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
-    ctx = crt.Context(1280, 720); hs.upload(ctx); ctx.render(1, 26 * 64, 1); a = ctx.accumulator(); ra = ctx.counters()["rays"]; ctx.close()
+    ctx = crt.Context(1280, 720); hs.upload(ctx); ctx.render(1, 20 * 64, 1); a = ctx.accumulator(); ra = ctx.counters()["rays"]; assert ctx.timing()["pool_launches"] == 1; ctx.close()
     monkeypatch.setenv("CRT_RENDER_KERNEL", "tiles")
-    ctx = crt.Context(1280, 720); hs.upload(ctx); ctx.render(1, 26 * 64, 1); b = ctx.accumulator(); rb = ctx.counters()["rays"]; ctx.close()
+    ctx = crt.Context(1280, 720); hs.upload(ctx); ctx.render(1, 20 * 64, 1); b = ctx.accumulator(); rb = ctx.counters()["rays"]; assert ctx.timing()["pool_launches"] == 0; ctx.close()
     assert np.array_equal(a, b) and ra == rb
 
 
