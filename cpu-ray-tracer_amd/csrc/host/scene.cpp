@@ -1,5 +1,6 @@
 // scene.cpp — scene assembly on the CPU (as the reference's scene constructors do) and the Renderer facade.
 #include "scene.h"
+#include <chrono>
 
 #include <stdexcept>
 
@@ -241,8 +242,14 @@ void Renderer::TickWhitted()
 
 void Renderer::Tick(float deltaTime)   // renderer.cpp:144-168
 {
-    if (animating) anim_time += deltaTime * 0.002f;
-    Render(1);
+    if (animating) anim_time += deltaTime * 0.002f;                                              // :147 (Render applies SetTime + ClearAccumulator)
+    const auto t0 = std::chrono::steady_clock::now();
+    Render(1);                                                                                  // the tile jobs (:149-153) + energy (:155-157)
+    // performance report - running average - ms, frames/s, primary rays per ms (:159-161; the UI labels the last one "Mrays/s")
+    const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    m_avg = (1 - m_alpha) * m_avg + m_alpha * ms;
+    if (m_alpha > 0.05f) m_alpha *= 0.75f;
+    m_fps = 1000.0f / m_avg; m_rps = (float)(width * height) / m_avg;
 }
 
 } // namespace crt

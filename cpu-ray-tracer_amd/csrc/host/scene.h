@@ -118,6 +118,8 @@ public:
     int spp = 1, passes = 1;
     bool animating = false;
     float energy = 0, anim_time = 0;
+    // performance report of Tick (renderer.cpp:159-161): running average of the frame time in ms, frames per second, primary rays per ms
+    float m_avg = 10, m_fps = 0, m_rps = 0, m_alpha = 1;
     int depthLimit = 5;
     Surface* screen = nullptr; Surface ownScreen;
     crt_ctx* ctx = nullptr;
