@@ -160,6 +160,8 @@ def main():
     counts = {k: v / args.steps for k, v in sctx.counters().items()}
     sctx.close()
 
+    collective = {"used": args.reduce}
+
     def run(n_steps):
         """n_steps steps = 64*n_steps frames submitted as one job: the back end renders up to 64 windows per render_tiles_kernel
         launch and accumulates them in frame order; one sync (and, for N > 1, ONE RCCL all-reduce of the float4 accumulators
@@ -168,8 +170,12 @@ def main():
         ctx.render(window(0, n_steps), SPP * n_steps, 1)
         ctx.sync()
         if dist is not None:
-            if args.reduce == "reduce":
-                crt.reduce_accumulator(acc, dist, 0)
+            if collective["used"] == "reduce":
+                try:
+                    crt.reduce_accumulator(acc, dist, 0)
+                except RuntimeError:                     # a backend without reduce for device tensors (gloo rehearsals): all_reduce from now on
+                    collective["used"] = "all_reduce"
+                    crt.allreduce_accumulator(acc, dist)
             else:
                 crt.allreduce_accumulator(acc, dist)
             torch.cuda.synchronize()
@@ -258,9 +264,9 @@ def main():
                                "+ ordered accumulate), one sync at the end%s"
                                % (args.scene, "TLASFileScene" if args.kind else "FileScene", W, H, SPP, SPP, args.steps, launches,
                                   "" if world == 1 else ("; every one of the %d ranks renders its own %d windows, ONE RCCL all-reduce of the float4 accumulator closes the job" % (world, args.steps)
-                                                         if args.split == "frames" else "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE RCCL %s of the float4 accumulator closes the job" % (world, args.reduce))),
+                                                         if args.split == "frames" else "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE RCCL %s of the float4 accumulator closes the job" % (world, collective["used"]))),
                    "latency_ms_single_step": round(single_ms, 3) if single_ms else None,
-                   "collective": None if world == 1 else args.reduce, "rccl_ranks": None if dist is None else dist.get_world_size(), "backend": None if dist is None else dist.get_backend(),
+                   "collective": None if world == 1 else collective["used"], "rccl_ranks": None if dist is None else dist.get_world_size(), "backend": None if dist is None else dist.get_backend(),
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
                    "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},
         "single_render": None if not single_ms else {"ms": round(single_ms, 3), "mrays_s": round(counts["rays"] / single_ms / 1e3, 1),
