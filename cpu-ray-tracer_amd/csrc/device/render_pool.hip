@@ -54,13 +54,13 @@ constexpr uint32_t kQueueMask = 127u;                            // queues are r
 
 #ifdef CRT_POOL_STAMPS
 // diagnostic build only (-DCRT_POOL_STAMPS): shader-clock time of the sections of the loop, summed over all waves into the (otherwise unused) counter
-// slots 2..6 of a non-counting launch: [2] walk incl. the wait for the records, [3] swap out / in + record loads, [4] END passes, [5] BOUNCE passes, [6] trips
+// slots 2..6 of a non-counting launch: [2] walk (incl. the wait for the records) + swap out / in + record loads, [3] unused, [4] END passes, [5] BOUNCE passes, [6] trips
 #define CRT_PSTAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
 #else
 #define CRT_PSTAMP(var)
 #endif
-template <int KIND, bool COUNT, int S>
-__global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
+template <int KIND, bool COUNT, int S, int SETS>
+__global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
                                                              unsigned long long* __restrict__ tileClocks, const uint32_t* __restrict__ tileOrder,
                                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                              uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t groups)
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
 
     // `cur` and the stack entries of this kernel are 16-bit references (layout.h: ref16 — the children's are stored next to the 32-bit ones in
     // every NodePair); 2 bytes per stack entry instead of 4 is what lets 128 parked streams + the stacks fit 4 waves per SIMD
-    uint16_t* stk = reinterpret_cast<uint16_t*>(lds) + lane;                     // traversal stack of the stream resident in this lane: entry i at stk[i * 64]
-    uint32_t* st = lds + sc.stackDepth * 32u;                                    // parked stream state (behind stackDepth * 64 two-byte entries)
+    uint16_t* stk0 = reinterpret_cast<uint16_t*>(lds) + lane;                    // traversal stack of a stream resident in this lane: entry i at stk[i * 64] (one stack per resident set)
+    uint32_t* st = lds + sc.stackDepth * 32u * (uint32_t)SETS;                   // parked stream state (behind SETS * stackDepth * 64 two-byte entries)
     float* stf = reinterpret_cast<float*>(st);
     uint8_t* qEnd = reinterpret_cast<uint8_t*>(st + F_COUNT * S);
     uint8_t* qBnc = qEnd + 128, * qRdy = qEnd + 256;
@@ -104,15 +104,21 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
     }
     uint32_t endH = 0, endT = nStreams, bncH = 0, bncT = 0, rdyH = 0, rdyT = 0;  // queue heads / tails (wave-uniform)
 
-    // the stream resident in this lane
-    bool res = false; uint32_t sid = 0;
-    uint32_t cur = kRefDone, sp = 0;
-    f3 tO = camPos, tD = camPos, trD = camPos;                                   // ray in the space of the structure being walked
-    bool rayFinite = true;
-    Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
-    rec4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;                           // pre-loaded record of `cur`
+    // The streams resident in this lane: SETS of them (1, or 2 = "dual" mode).  With two sets the walk of set A runs while the record loads of set B
+    // fly and vice versa, so a wave hides its own load latency, and a wave's 128 streams can all be resident at once (no stream waits for a lane).
+    struct Res {
+        bool res; uint32_t sid, cur, sp; f3 tO, tD, trD; bool rayFinite; Hit h; rec4 q0, q1, q2, q3; uint16_t* stk;
+    };
+    Res R[SETS];
+#pragma unroll
+    for (int k = 0; k < SETS; k++) {
+        R[k].res = false; R[k].sid = 0; R[k].cur = kRefDone; R[k].sp = 0; R[k].tO = R[k].tD = R[k].trD = camPos; R[k].rayFinite = true;
+        R[k].h.t = 1e34f; R[k].h.u = 0; R[k].h.v = 0; R[k].h.objIdx = -1; R[k].h.triIdx = -1;
+        R[k].q0 = rec4{0, 0, 0, 0}; R[k].q1 = R[k].q0; R[k].q2 = R[k].q0; R[k].q3 = R[k].q0;
+        R[k].stk = stk0 + (uint32_t)k * sc.stackDepth * 64u;
+    }
 
-#define CRT_TOP() (stk[(sp ? sp - 1u : 0u) * 64u])
+#define CRT_TOP() (r.stk[(r.sp ? r.sp - 1u : 0u) * 64u])
 
     // ---- the start of a stream's next scene.FindNearest, shared by both shading passes: normalise, reciprocal direction, light quad,
     // floor plane, root step; parks the new ray and queues the stream (READY, or END / BOUNCE when the ray never enters the tree)
@@ -164,149 +170,156 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
 #ifdef CRT_POOL_STAMPS
     unsigned long long pst[5] = {0, 0, 0, 0, 0};
 #endif
-    for (;;) {
-        CRT_PSTAMP(p0);
-        // ---------------- D. walk: state ballots of the resident streams, then the phases that have lanes ------------------------------
-        const bool isNode = res && (KIND == 1 ? (((cur >> 15) ^ (cur >> 14)) & 1u) != 0u : (cur & kRef16TagMask) == kRef16Interior);
-        const bool isTri = res && cur != kRefDone && (cur & kRef16TagMask) == 0u;
-        const bool isTlas = (KIND == 1) && res && (cur & kRef16TagMask) == kRef16TlasLeaf;
+    // ---------------- D. walk: the phases of one resident set (TLAS leaf / NODE / TRI), on the records loaded by its previous trip ----------------
+    auto walk = [&](Res& r) {
+        const bool isNode = r.res && (KIND == 1 ? (((r.cur >> 15) ^ (r.cur >> 14)) & 1u) != 0u : (r.cur & kRef16TagMask) == kRef16Interior);
+        const bool isTri = r.res && r.cur != kRefDone && (r.cur & kRef16TagMask) == 0u;
+        const bool isTlas = (KIND == 1) && r.res && (r.cur & kRef16TagMask) == kRef16TlasLeaf;
         const bool runNode = __builtin_amdgcn_ballot_w64(isNode) != 0ull, runTri = __builtin_amdgcn_ballot_w64(isTri) != 0ull;
         const bool runTlas = (KIND == 1) && __builtin_amdgcn_ballot_w64(isTlas) != 0ull;
         // The record loads issued at the end of the previous trip are first needed here.  Naming all four tuples in one
         // empty asm keeps the register allocator from splitting a loaded tuple across the back-edge.
-        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
-
+        asm volatile("" : "+v"(r.q0), "+v"(r.q1), "+v"(r.q2), "+v"(r.q3));
         if (KIND == 1 && runTlas && isTlas) {
             // ---------------- TLAS leaf (infra/tlas_bvh.cpp:91-95) -> enter the BLAS (BLASBVH::Intersect, blas_bvh.cpp:376-381) ----------
             if (COUNT) { cn.tlas++; cn.visits++; }
-            const f3 O = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
-            const f3 D = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
-            to_object_space(q0, q1, q2, O, D, tO, tD, trD);
-            rayFinite = finite3(trD);
-            stk[sp * 64u] = (uint16_t)kRef16Return; sp++;
-            const uint32_t next = asu(q3.y);                                       // Instance::rootRef16
+            const f3 O = mk3(stf[F_OX * S + r.sid], stf[F_OY * S + r.sid], stf[F_OZ * S + r.sid]);
+            const f3 D = mk3(stf[F_DX * S + r.sid], stf[F_DY * S + r.sid], stf[F_DZ * S + r.sid]);
+            to_object_space(r.q0, r.q1, r.q2, O, D, r.tO, r.tD, r.trD);
+            r.rayFinite = finite3(r.trD);
+            r.stk[r.sp * 64u] = (uint16_t)kRef16Return; r.sp++;
+            const uint32_t next = asu(r.q3.y);                                     // Instance::rootRef16
             if (COUNT && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
-            cur = next;
+            r.cur = next;
         }
         if (runNode) {
             // ---------------- NODE phase (infra/bvh.cpp:244-257) ------------------------------------------------------------------------
-            const bool allFinite = __builtin_amdgcn_ballot_w64(isNode && !rayFinite) == 0ull;
+            const bool allFinite = __builtin_amdgcn_ballot_w64(isNode && !r.rayFinite) == 0ull;
             if (isNode) {
-                if (COUNT) { if (KIND == 1 && (cur & kRef16TlasBit) != 0u) cn.tlas++; else cn.interior++; }
+                if (COUNT) { if (KIND == 1 && (r.cur & kRef16TlasBit) != 0u) cn.tlas++; else cn.interior++; }
                 uint32_t top = CRT_TOP();                                          // speculative: lands during the slab arithmetic
                 float d1, d2;
-                if (allFinite) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
-                else { d1 = box_exact(q0, q1, tO, trD, h.t); d2 = box_exact(q2, q3, tO, trD, h.t); }
+                if (allFinite) { d1 = box_fast(r.q0, r.q1, r.tO, r.trD, r.h.t); d2 = box_fast(r.q2, r.q3, r.tO, r.trD, r.h.t); }
+                else { d1 = box_exact(r.q0, r.q1, r.tO, r.trD, r.h.t); d2 = box_exact(r.q2, r.q3, r.tO, r.trD, r.h.t); }
                 const bool sw = d1 > d2;                                           // near child first (strict >: ties keep child 1)
                 const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
-                const uint32_t rn = sw ? asu(q3.w) : asu(q1.w), rf = sw ? asu(q1.w) : asu(q3.w);   // the children's ref16
-                stk[sp * 64u] = (uint16_t)rf;                                      // dead store unless `push`
+                const uint32_t rn = sw ? asu(r.q3.w) : asu(r.q1.w), rf = sw ? asu(r.q1.w) : asu(r.q3.w);   // the children's ref16
+                r.stk[r.sp * 64u] = (uint16_t)rf;                                  // dead store unless `push`
                 const bool hitN = dn != 1e30f, push = hitN && df != 1e30f;
-                bool pop = !hitN && sp != 0u;
+                bool pop = !hitN && r.sp != 0u;
                 uint32_t next = hitN ? rn : (pop ? top : kRefDone);
-                sp = sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
+                r.sp = r.sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
                 if (KIND == 1 && next == kRef16Return) {                             // BLAS finished: back to the world-space ray, pop the TLAS entry below
-                    tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
-                    tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
-                    trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
-                    rayFinite = finite3(trD);
-                    pop = sp != 0u; top = CRT_TOP();
-                    next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
+                    r.tO = mk3(stf[F_OX * S + r.sid], stf[F_OY * S + r.sid], stf[F_OZ * S + r.sid]);
+                    r.tD = mk3(stf[F_DX * S + r.sid], stf[F_DY * S + r.sid], stf[F_DZ * S + r.sid]);
+                    r.trD = mk3(stf[F_RX * S + r.sid], stf[F_RY * S + r.sid], stf[F_RZ * S + r.sid]);
+                    r.rayFinite = finite3(r.trD);
+                    pop = r.sp != 0u; top = CRT_TOP();
+                    next = pop ? top : kRefDone; r.sp -= pop ? 1u : 0u;
                 }
                 if (COUNT && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
-                cur = next;
+                r.cur = next;
             }
         }
         if (runTri && isTri) {
             // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:203-222, 232-243) -------------------------------
             if (COUNT) cn.tri++;
             uint32_t top = CRT_TOP();
-            hit_tri(q0, q1, q2, tO, tD, h);
-            const bool more = asu(q2.w) > 1u;                                      // next LeafTri of this leaf (48 B = 3 units)
-            bool pop = !more && sp != 0u;
-            uint32_t next = more ? cur + 1u : (pop ? top : kRefDone);     // the leaf's next LeafTri is the next index
-            sp -= pop ? 1u : 0u;
+            hit_tri(r.q0, r.q1, r.q2, r.tO, r.tD, r.h);
+            const bool more = asu(r.q2.w) > 1u;                                    // the leaf's next LeafTri is the next index
+            bool pop = !more && r.sp != 0u;
+            uint32_t next = more ? r.cur + 1u : (pop ? top : kRefDone);
+            r.sp -= pop ? 1u : 0u;
             if (KIND == 1 && next == kRef16Return) {
-                tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
-                tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
-                trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
-                rayFinite = finite3(trD);
-                pop = sp != 0u; top = CRT_TOP();
-                next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
+                r.tO = mk3(stf[F_OX * S + r.sid], stf[F_OY * S + r.sid], stf[F_OZ * S + r.sid]);
+                r.tD = mk3(stf[F_DX * S + r.sid], stf[F_DY * S + r.sid], stf[F_DZ * S + r.sid]);
+                r.trD = mk3(stf[F_RX * S + r.sid], stf[F_RY * S + r.sid], stf[F_RZ * S + r.sid]);
+                r.rayFinite = finite3(r.trD);
+                pop = r.sp != 0u; top = CRT_TOP();
+                next = pop ? top : kRefDone; r.sp -= pop ? 1u : 0u;
             }
             if (COUNT && !more && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
-            cur = next;
+            r.cur = next;
         }
-        CRT_PSTAMP(p1);
-        asm volatile("" ::: "memory");
-        // ---------------- A. swap out: streams whose walk is over park their hit and queue for shading ------------------------------
-        {
-            const bool fin = res && cur == kRefDone;
-            if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
-                bool toEnd = false;
-                if (fin) {
-                    stf[F_T * S + sid] = h.t; stf[F_U * S + sid] = h.u; stf[F_V * S + sid] = h.v;
-                    st[F_TRI * S + sid] = (uint32_t)h.triIdx;
-                    const uint32_t meta = st[F_META * S + sid];
-                    st[F_META * S + sid] = (meta & kMetaLowMask) | ((uint32_t)(h.objIdx + 1) << kMetaObjShift);
-                    const uint32_t depth = (meta >> kMetaDepthShift) & 7u;
-                    toEnd = h.objIdx == -1 || h.objIdx == 0 || (int)depth >= sc.depthLimit;
-                    res = false;
-                }
-                const uint64_t mE = __builtin_amdgcn_ballot_w64(fin && toEnd), mB = __builtin_amdgcn_ballot_w64(fin && !toEnd);
-                if (fin && toEnd) qEnd[(endT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mE >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mE, 0u))) & kQueueMask] = (uint8_t)sid;
-                if (fin && !toEnd) qBnc[(bncT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u))) & kQueueMask] = (uint8_t)sid;
-                endT += (uint32_t)__popcll(mE); bncT += (uint32_t)__popcll(mB);
+    };
+    // ---------------- A. swap out: streams whose walk is over park their hit and queue for shading ------------------------------
+    auto swap_out = [&](Res& r) {
+        const bool fin = r.res && r.cur == kRefDone;
+        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
+            bool toEnd = false;
+            if (fin) {
+                stf[F_T * S + r.sid] = r.h.t; stf[F_U * S + r.sid] = r.h.u; stf[F_V * S + r.sid] = r.h.v;
+                st[F_TRI * S + r.sid] = (uint32_t)r.h.triIdx;
+                const uint32_t meta = st[F_META * S + r.sid];
+                st[F_META * S + r.sid] = (meta & kMetaLowMask) | ((uint32_t)(r.h.objIdx + 1) << kMetaObjShift);
+                const uint32_t depth = (meta >> kMetaDepthShift) & 7u;
+                toEnd = r.h.objIdx == -1 || r.h.objIdx == 0 || (int)depth >= sc.depthLimit;
+                r.res = false;
             }
+            const uint64_t mE = __builtin_amdgcn_ballot_w64(fin && toEnd), mB = __builtin_amdgcn_ballot_w64(fin && !toEnd);
+            if (fin && toEnd) qEnd[(endT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mE >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mE, 0u))) & kQueueMask] = (uint8_t)r.sid;
+            if (fin && !toEnd) qBnc[(bncT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u))) & kQueueMask] = (uint8_t)r.sid;
+            endT += (uint32_t)__popcll(mE); bncT += (uint32_t)__popcll(mB);
         }
-        asm volatile("" ::: "memory");          // (the sections exchange stream state through LDS across lanes: nothing is carried over in registers)
-        const uint64_t mRes = __builtin_amdgcn_ballot_w64(res);
-        const uint32_t nRes = (uint32_t)__popcll(mRes);
+    };
+    // ---------------- C. swap in: free lanes take the next READY streams; E. the record loads of the set (consumed by its next walk) ----
+    auto swap_in_and_load = [&](Res& r) {
+        const uint32_t nRdy = rdyT - rdyH;
+        const uint64_t mFree = ~__builtin_amdgcn_ballot_w64(r.res);
+        if (nRdy != 0u && mFree != 0ull) {
+            const uint32_t myRank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mFree >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mFree, 0u));
+            if (!r.res && myRank < nRdy) {
+                r.sid = qRdy[(rdyH + myRank) & kQueueMask];
+                r.tO = mk3(stf[F_OX * S + r.sid], stf[F_OY * S + r.sid], stf[F_OZ * S + r.sid]);
+                r.tD = mk3(stf[F_DX * S + r.sid], stf[F_DY * S + r.sid], stf[F_DZ * S + r.sid]);
+                r.trD = mk3(stf[F_RX * S + r.sid], stf[F_RY * S + r.sid], stf[F_RZ * S + r.sid]);
+                r.h.t = stf[F_T * S + r.sid]; r.h.objIdx = (int)(st[F_META * S + r.sid] >> kMetaObjShift) - 1; r.h.u = 0; r.h.v = 0; r.h.triIdx = -1;
+                r.cur = st[F_CUR * S + r.sid];
+                const uint32_t pend = st[F_PEND * S + r.sid];
+                r.stk[0] = (uint16_t)pend; r.sp = pend ? 1u : 0u;                  // a dead store unless the far root child was hit
+                r.rayFinite = finite3(r.trD);
+                r.res = true;
+            }
+            const uint32_t nFree = (uint32_t)__popcll(mFree);
+            rdyH += nRdy < nFree ? nRdy : nFree;
+        }
+        const bool want = r.res && r.cur != kRefDone;
+        // record offset of a 16-bit reference: index * record size + section base (layout.h)
+        const uint32_t idx = r.cur & kRef16IndexMask;
+        uint32_t oa = (r.cur & kRef16Interior) ? idx * 64u : sc.leafOff - 48u + idx * 48u;     // NodePair | LeafTri
+        if (KIND == 1 && (r.cur & kRef16TlasBit) != 0u)
+            oa = (r.cur & kRef16Interior) ? sc.instOff + idx * 128u : sc.tlasPairOff + idx * 64u;   // TLAS leaf: Instance {invT rows, ids} | TLAS interior: its child pair
+        uint32_t ob = oa + 32u;
+        if (!want) { oa = 0u; ob = 32u; }
+        if (__builtin_amdgcn_ballot_w64(want) != 0ull) { r.q0 = ldg(geom, oa); r.q1 = ldg(geom, oa + 16u); r.q2 = ldg(geom, ob); r.q3 = ldg(geom, ob + 16u); }
+    };
+
+    for (;;) {
+        CRT_PSTAMP(p0);
+        uint32_t nRes = 0;
+#pragma unroll
+        for (int k = 0; k < SETS; k++) {
+            walk(R[k]);
+            asm volatile("" ::: "memory");          // (the sections exchange stream state through LDS across lanes: nothing is carried over in registers)
+            swap_out(R[k]);
+            asm volatile("" ::: "memory");
+            if (k + 1 < SETS) { swap_in_and_load(R[k]); asm volatile("" ::: "memory"); }     // (the last set swaps in after the exit test)
+            nRes += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(R[k].res));
+        }
         {
             const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH;
             if (nEnd + nBnc + nRdy + nRes == 0u) break;
             if (COUNT) trips++;
         }
-        asm volatile("" ::: "memory");
-        // ---------------- C. swap in: free lanes take the next READY streams -----------------------------------------------------------
-        {
-            const uint32_t nRdy = rdyT - rdyH;
-            const uint64_t mFree = ~__builtin_amdgcn_ballot_w64(res);
-            if (nRdy != 0u && mFree != 0ull) {
-                const uint32_t myRank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mFree >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mFree, 0u));
-                if (!res && myRank < nRdy) {
-                    sid = qRdy[(rdyH + myRank) & kQueueMask];
-                    tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
-                    tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
-                    trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
-                    h.t = stf[F_T * S + sid]; h.objIdx = (int)(st[F_META * S + sid] >> kMetaObjShift) - 1; h.u = 0; h.v = 0; h.triIdx = -1;
-                    cur = st[F_CUR * S + sid];
-                    const uint32_t pend = st[F_PEND * S + sid];
-                    stk[0] = (uint16_t)pend; sp = pend ? 1u : 0u;                            // a dead store unless the far root child was hit
-                    rayFinite = finite3(trD);
-                    res = true;
-                }
-                const uint32_t nFree = (uint32_t)__popcll(mFree);
-                rdyH += nRdy < nFree ? nRdy : nFree;
-            }
-        }
-        // ---------------- E. issue the record loads of the resident streams (consumed by the next trip) ----------------------------------
-        {
-            const bool want = res && cur != kRefDone;
-            // record offset of a 16-bit reference: index * record size + section base (layout.h)
-            const uint32_t idx = cur & kRef16IndexMask;
-            uint32_t oa = (cur & kRef16Interior) ? idx * 64u : sc.leafOff - 48u + idx * 48u;     // NodePair | LeafTri
-            if (KIND == 1 && (cur & kRef16TlasBit) != 0u)
-                oa = (cur & kRef16Interior) ? sc.instOff + idx * 128u : sc.tlasPairOff + idx * 64u;   // TLAS leaf: Instance {invT rows, ids} | TLAS interior: its child pair
-            uint32_t ob = oa + 32u;
-            if (!want) { oa = 0u; ob = 32u; }
-            if (__builtin_amdgcn_ballot_w64(want) != 0ull) { q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, ob); q3 = ldg(geom, ob + 16u); }
-        }
+        swap_in_and_load(R[SETS - 1]);
         CRT_PSTAMP(p2);
         asm volatile("" ::: "memory");
         {
             // ---------------- B. shading passes (their latency-free arithmetic also covers the record loads just issued) --------------------
-            const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH, nRes = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(res));
+            uint32_t nResNow = 0;
+#pragma unroll
+            for (int k = 0; k < SETS; k++) nResNow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(R[k].res));
+            const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH, nRes = nResNow;
             // a shading pass waits for a full wavefront of streams unless the walking side runs dry
             const bool starving = nRes + nRdy < (uint32_t)CRT_POOL_STARVE;
             const bool runEnd = nEnd >= (uint32_t)CRT_POOL_SHADE_MIN || (starving && nEnd > 0u && nEnd >= nBnc);
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                 new_ray(act, s, v, false, O, seed, item | ((uint32_t)(depth + 1) << kMetaDepthShift) | (newInside ? kMetaInside : 0u));
             }
 #ifdef CRT_POOL_STAMPS
-            { CRT_PSTAMP(p4); pst[0] += p1 - p0; pst[1] += p2 - p1; pst[3] += p4 - p3; pst[4]++; }
+            { CRT_PSTAMP(p4); pst[0] += p2 - p0; pst[3] += p4 - p3; pst[4]++; }
 #endif
         }
     }
@@ -515,7 +528,10 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
 #define CRT_POOL_STREAMS 128
 #endif
 extern "C" uint32_t crt_pool_streams(uint32_t frames) { return frames > 64u ? (uint32_t)CRT_POOL_STREAMS : 64u; }
-extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackDepth, uint32_t streams) { return stackDepth * 64u * 2u + crt::F_COUNT * streams * 4u + 3u * 128u; }
+#ifndef CRT_POOL_SETS
+#define CRT_POOL_SETS 1            // resident sets per lane in launches of more than 64 frames (2 = dual mode)
+#endif
+extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackDepth, uint32_t streams, uint32_t sets) { return sets * stackDepth * 64u * 2u + crt::F_COUNT * streams * 4u + 3u * 128u; }
 // bytes of throughput-factor scratch a launch of `windows` 64-frame windows needs behind its sample slab (15 floats per stream; a wave's
 // group of streams may reach past the last window, hence 128 stream slots per window)
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t tileCount) { return (size_t)tileCount * 128u * 15u * 4u; }
@@ -530,9 +546,10 @@ extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, v
     const uint32_t groups = (frames + S - 1u) / S;
     if ((unsigned long long)tileCount * groups > 0x7fffffffull) return hipErrorInvalidValue;
     dim3 grid(tileCount * groups), block(64);
-    const uint32_t ldsBytes = crt_pool_lds_bytes(sc->stackDepth, S);
-#define CRT_LAUNCH(K, C, SS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups)
-#define CRT_LAUNCH_S(K, C) do { if (S == 64u) CRT_LAUNCH(K, C, 64); else CRT_LAUNCH(K, C, CRT_POOL_STREAMS); } while (0)
+    const uint32_t sets = S == 64u ? 1u : (uint32_t)CRT_POOL_SETS;
+    const uint32_t ldsBytes = crt_pool_lds_bytes(sc->stackDepth, S, sets);
+#define CRT_LAUNCH(K, C, SS, NS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS, NS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups)
+#define CRT_LAUNCH_S(K, C) do { if (S == 64u) CRT_LAUNCH(K, C, 64, 1); else CRT_LAUNCH(K, C, CRT_POOL_STREAMS, CRT_POOL_SETS); } while (0)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH_S(0, true); else CRT_LAUNCH_S(0, false); }
     else { if (collectStats) CRT_LAUNCH_S(1, true); else CRT_LAUNCH_S(1, false); }
 #undef CRT_LAUNCH_S

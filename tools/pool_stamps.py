@@ -12,5 +12,5 @@ ctx.render(1, 1024, 1); ctx.sync(); ctx.reset_counters(); ctx.render(1, 1024, 1)
 c = ctx.counters(); tm = ctx.timing()
 walk, swap, end, bnc, trips = c["interior_iters"], c["leaf_iters"], c["tri_tests"], c["tlas_iters"], c["blas_visits"]
 tot = walk + swap + end + bnc
-print("%s: trips %.2fM per window; wave time: walk %.1f%% swap+loads %.1f%% END passes %.1f%% BOUNCE passes %.1f%%; cycles/trip: walk %.0f swap %.0f end %.0f bounce %.0f"
-      % (xml, trips / 16e6, 100 * walk / tot, 100 * swap / tot, 100 * end / tot, 100 * bnc / tot, walk / trips, swap / trips, end / trips, bnc / trips))
+print("%s: trips %.2fM per window; wave time: walk + swap + loads %.1f%% END passes %.1f%% BOUNCE passes %.1f%%; cycles/trip: walk+swap %.0f end %.0f bounce %.0f"
+      % (xml, trips / 16e6, 100 * (walk + swap) / tot, 100 * end / tot, 100 * bnc / tot, (walk + swap) / trips, end / trips, bnc / trips))
