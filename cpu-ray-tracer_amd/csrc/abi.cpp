@@ -897,13 +897,21 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         // windows (20 windows: 81.0 ms pool, 87.6 ms tiles), TLAS scene at ~28, watch-tower 1920x1080 at 7 — 56 000 ... 100 000 (tile, window) pairs; the
         // threshold sits at the low end of that range.
         const bool pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * ((nf + 63u) / 64u) >= c->poolMinWaves && (c->poolMinWaves == 0 || nf > 64u);
-        if (pool) c->poolLaunches++;
-        if (pool)
-            HIPCK(c, crt_launch_render_pool(&c->hScene, slab, (char*)slab + (size_t)((nf + 63u) / 64u) * sample_bytes_per_window(c, passes), c->dCounters, c->dTileClocks, c->dTileOrder,
-                                            c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->cfg.collectStats, st));
+        hipError_t le;
+        if (getenv("CRT_DEBUG_FAIL_LAUNCH")) le = hipErrorInvalidConfiguration;       // tests: the runtime refuses the launch
+        else if (pool)
+            le = crt_launch_render_pool(&c->hScene, slab, (char*)slab + (size_t)((nf + 63u) / 64u) * sample_bytes_per_window(c, passes), c->dCounters, c->dTileClocks, c->dTileOrder,
+                                        c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->cfg.collectStats, st);
         else
-            HIPCK(c, crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, narrow, c->narrowLanes, st));
+            le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, narrow, c->narrowLanes, st);
+        if (le != hipSuccess) {
+            // a launch that failed has rendered nothing: take its timing pair back (a half-recorded pair would poison crt_get_timing), leave the accumulator
+            // and the region bookkeeping untouched — the frames before it are in, this one and the rest are not — and report
+            c->evPool.push_back(c->evRender.back()); c->evRender.pop_back();
+            return c->hip(le, pool ? "launch of render_pool_kernel" : "launch of render_tiles_kernel");
+        }
+        if (pool) c->poolLaunches++;
         HIPCK(c, hipEventRecord(ev.b, st));
         // ordered accumulation on the main stream (frame order = launch order), behind this launch
         HIPCK(c, hipStreamWaitEvent(c->stream, ev.b, 0));

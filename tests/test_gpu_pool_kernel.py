@@ -97,3 +97,23 @@ def test_timing_events_stay_bounded_in_a_tick_loop(crt):
     assert ctx.L.crt_debug_live_events(ctx.h) <= 4 * (64 + 600 // 6)          # bounded, far below the 2400 events of 600 launches
     t = ctx.timing()
     assert t["render_launches"] == 600 and t["render_kernel_ms"] > 0
+
+
+def test_failing_launch_is_reported_and_leaves_the_context_usable(crt, orc, monkeypatch):
+    """a render launch the runtime refuses (simulated: CRT_DEBUG_FAIL_LAUNCH) -> CRT_ERR_DEVICE from crt_render, nothing half-recorded:
+    timing still answers, the frames rendered before it are in the accumulator, and the same context goes on rendering correctly"""
+    hs = crt.HostScene(scene_path("cube_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(32, 32)
+    hs.upload(ctx)
+    ctx.render(1, 1, 1)
+    monkeypatch.setenv("CRT_DEBUG_FAIL_LAUNCH", "1")
+    with pytest.raises(crt.CrtError) as e:
+        ctx.render(2, 1, 1)
+    assert e.value.code == -2                                   # CRT_ERR_DEVICE
+    t = ctx.timing()
+    assert t["render_launches"] == 1 and t["render_kernel_ms"] > 0
+    monkeypatch.delenv("CRT_DEBUG_FAIL_LAUNCH")
+    ctx.render(2, 1, 1)
+    o, _ = orc.load_scene(scene_path("cube_scene.xml"), 0, ASSETS)
+    o.renderer_init(32, 32); o.render(2, 1)
+    assert np.array_equal(ctx.accumulator(), o.accumulator())
