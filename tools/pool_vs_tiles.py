@@ -14,14 +14,15 @@ frames = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 passes = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 sc = crt.HostScene(os.path.join(A, "scenes", xml), kind, A)
 out = {}
-for k in ("tiles", "pool"):
+for k in ("tiles", os.environ.get("CRT_COMPARE", "pool_always")):
     os.environ["CRT_RENDER_KERNEL"] = k
     ctx = crt.Context(W, H); sc.upload(ctx)
     ctx.render(1, frames, passes); out[k] = ctx.accumulator().copy(); cn = ctx.counters(); ctx.close()
     print(k, {a: cn[a] for a in ("rays", "primary", "mesh_hits")}, "finite", np.isfinite(out[k]).all())
-d = out["pool"] != out["tiles"]
+other = os.environ.get("CRT_COMPARE", "pool_always")
+d = out[other] != out["tiles"]
 print("differing pixels:", int(d.any(axis=2).sum()), "of", W * H)
 if d.any():
     ys, xs = np.nonzero(d.any(axis=2))
     for y, x in list(zip(ys, xs))[:8]:
-        print(" (%d,%d) pool %s tiles %s" % (x, y, out["pool"][y, x], out["tiles"][y, x]))
+        print(" (%d,%d) pool %s tiles %s" % (x, y, out[other][y, x], out["tiles"][y, x]))
