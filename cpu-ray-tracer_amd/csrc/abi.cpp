@@ -38,6 +38,7 @@ struct AltAccelDev {
     int32_t res[3]; float cell[3]; float lo[3], hi[3]; const uint32_t* cellStart; const int32_t* cellRefs;
 };
 }
+extern "C" hipError_t crt_launch_check_reciprocals(unsigned long long*, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest_alt(int, const crt::Scene*, const crt::AltAccelDev*, const void*, void*, uint32_t, hipStream_t);
 
 namespace {
@@ -1149,6 +1150,22 @@ int crt_get_tile_clocks(crt_ctx* c, uint64_t* out)
 // diagnostic builds (-DCRT_STAMPS) only: 16 extra words per tile behind the tile clocks (not part of the public ABI)
 // tests: HIP timing events currently held by the context (bounded: completed launches are folded into totals, see fold_completed)
 extern "C" int crt_debug_live_events(crt_ctx* c) { return c ? (int)(2 * (c->evRender.size() + c->evAcc.size() + c->evPool.size())) : -1; }
+
+// tests: the device's short reciprocals (dev_common.h rcp_exact*) against the IEEE division over all 2^32 inputs; out[4] = {inputs, differences x 3}
+extern "C" int crt_debug_check_reciprocals(crt_ctx* c, uint64_t* out)
+{
+    if (!c || !out) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    unsigned long long* d = nullptr;
+    HIPCK(c, hipMalloc(&d, 32));
+    hipError_t e = hipMemsetAsync(d, 0, 32, c->stream);
+    if (e == hipSuccess) e = crt_launch_check_reciprocals(d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, 32, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCK(c, e);
+    return CRT_OK;
+}
 
 extern "C" int crt_debug_tile_stamps(crt_ctx* c, uint64_t* out)
 {

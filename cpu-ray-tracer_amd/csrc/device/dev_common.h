@@ -25,7 +25,39 @@ __device__ __forceinline__ f3 operator*(f3 a, float b) { return mk3(a.x * b, a.y
 __device__ __forceinline__ f3 operator*(float b, f3 a) { return mk3(b * a.x, b * a.y, b * a.z); }
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ f3 normalize3(f3 v) { float inv = 1.0f / __builtin_sqrtf(dot3(v, v)); return v * inv; }
+// 1.0f / x in three instructions instead of the eleven of the IEEE sequence (v_div_scale .. v_div_fixup): v_rcp_f32 (1 ulp) followed by one Newton
+// step r + r * (1 - x * r), two fma, IS the correctly rounded quotient for every 2^-126 <= |x| <= 2^126 — compared with 1.0f / x over all
+// 4 227 858 434 such inputs on gfx950 (tools/microbench/exact_rcp.hip: 0 differences) — so results stay bit-identical.  If any active lane of the
+// wave holds another input (0, denormal, > 2^126, inf, NaN) the wave takes the IEEE division instead (a scalar branch: never if-converted).
+// (-DCRT_IEEE_DIV builds the IEEE sequence everywhere: the A/B switch of tools/ab_bench.py)
+#ifdef CRT_IEEE_DIV
+__device__ __forceinline__ float rcp_nr(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float rcp_nr(float x) { const float r = __builtin_amdgcn_rcpf(x); return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r); }
+#endif
+__device__ __forceinline__ float rcp_exact(float x)
+{
+    float r = rcp_nr(x);
+    const float ax = __builtin_fabsf(x);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(ax >= 0x1p-126f && ax <= 0x1p126f)) != 0, 0)) r = 1.0f / x;
+    return r;
+}
+// the same where a caller only uses the result if |x| is far above 2^-126 (hit_tri: |det| >= 1e-4): one comparison
+__device__ __forceinline__ float rcp_exact_large(float x)
+{
+    float r = rcp_nr(x);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(x) <= 0x1p126f)) != 0, 0)) r = 1.0f / x;
+    return r;
+}
+__device__ __forceinline__ f3 rcp_exact3(f3 v)
+{
+    f3 r = mk3(rcp_nr(v.x), rcp_nr(v.y), rcp_nr(v.z));
+    const float ax = __builtin_fabsf(v.x), ay = __builtin_fabsf(v.y), az = __builtin_fabsf(v.z);
+    const bool okay = ax >= 0x1p-126f && ay >= 0x1p-126f && az >= 0x1p-126f && ax <= 0x1p126f && ay <= 0x1p126f && az <= 0x1p126f;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!okay) != 0, 0)) r = mk3(1.0f / v.x, 1.0f / v.y, 1.0f / v.z);
+    return r;
+}
+__device__ __forceinline__ f3 normalize3(f3 v) { float inv = rcp_exact(__builtin_sqrtf(dot3(v, v))); return v * inv; }
 __device__ __forceinline__ float min_std(float a, float b) { return (b < a) ? b : a; }   // std::min(a,b)
 __device__ __forceinline__ float max_std(float a, float b) { return (a < b) ? b : a; }   // std::max(a,b)
 __device__ __forceinline__ float min_tm(float a, float b) { return a < b ? a : b; }       // tmplmath fminf
@@ -190,7 +222,7 @@ __device__ __forceinline__ void hit_tri(rec4 a, rec4 b, rec4 c, f3 O, f3 D, Hit&
     const f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
     const f3 hh = cross3(D, e2);
     const float det = dot3(e1, hh);
-    const float f = 1 / det;
+    const float f = rcp_exact_large(det);                               // 1 / det; only used when |det| >= 1e-4 (the `ok` predicate)
     const f3 s = O - v0;
     const float u = f * dot3(s, hh);
     const f3 q = cross3(s, e1);
@@ -246,7 +278,7 @@ __device__ __forceinline__ void to_object_space(rec4 r0, rec4 r1, rec4 r2, f3 O,
     Do = mk3((D.x * r0.x + D.y * r0.y) + D.z * r0.z,
              (D.x * r1.x + D.y * r1.y) + D.z * r1.z,
              (D.x * r2.x + D.y * r2.y) + D.z * r2.z);
-    rDo = mk3(1 / Do.x, 1 / Do.y, 1 / Do.z);
+    rDo = rcp_exact3(Do);
 }
 
 // ------------------------------------------------------------------------------------------------------------

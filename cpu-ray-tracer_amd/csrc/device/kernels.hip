@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
             }
             // stage 5: the new ray (bounce or primary) and the start of its scene.FindNearest: light quad, floor plane, root step
             if (live) {
-                const float inv = 1.0f / __builtin_sqrtf(dot3(v, v));             // normalize(): v * (1 / sqrtf(dot(v, v)))
+                const float inv = rcp_exact(__builtin_sqrtf(dot3(v, v)));         // normalize(): v * (1 / sqrtf(dot(v, v)))
                 const f3 nv = norm ? v * inv : v;
 #if defined(CRT_DUP) && CRT_DUP == 5
                 { const f3 v2 = lnd3(v); sink3(v2 * (1.0f / __builtin_sqrtf(dot3(v2, v2)))); }
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                     depth++;
                     O = I + nv * CRT_EPS; inside = newInside;
                 } else O = camPos;
-                D = nv; rD = mk3(1 / nv.x, 1 / nv.y, 1 / nv.z);
+                D = nv; rD = rcp_exact3(nv);
 #if defined(CRT_DUP) && CRT_DUP == 4
                 { const f3 n2 = lnd3(nv); sink3(mk3(1 / n2.x, 1 / n2.y, 1 / n2.z)); }
 #endif
@@ -808,6 +808,34 @@ __global__ __launch_bounds__(64) void resolve_kernel(const float4* __restrict__ 
 // ------------------------------------------------------------------------------------------------------------
 // launch wrappers (called from abi.cpp)
 // ------------------------------------------------------------------------------------------------------------
+// self-check of dev_common.h's short reciprocals on the device at hand (tests/test_gpu_reciprocal.py through crt_debug_check_reciprocals): every one of the
+// 2^32 float bit patterns through rcp_exact / rcp_exact_large / rcp_exact3 against the IEEE division, bit for bit (two NaNs count as equal).
+// out = {inputs, rcp_exact differences, rcp_exact_large differences among |x| >= 1e-4 and NaN, rcp_exact3 differences}
+namespace crt {
+__device__ __forceinline__ bool same_bits(float a, float b) { return asu(a) == asu(b) || (a != a && b != b); }
+__global__ __launch_bounds__(256) void check_reciprocals_kernel(unsigned long long* out)
+{
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nthreads = gridDim.x * 256u;
+    unsigned long long n = 0, bad1 = 0, bad2 = 0, bad3 = 0;
+    for (uint64_t b = tid; b < (1ull << 32); b += nthreads) {
+        const float x = asf((uint32_t)b), want = 1.0f / x;
+        n++;
+        if (!same_bits(rcp_exact(x), want)) bad1++;
+        if (!(__builtin_fabsf(x) < 0.0001f) && !same_bits(rcp_exact_large(x), want)) bad2++;
+        // the other two components: a value from another part of the number line, and one that leaves the guard range now and then
+        const float y = asf((uint32_t)b * 2654435761u), z = asf(((uint32_t)b >> 7) * 40503u + 0x3f000000u);
+        const f3 r = rcp_exact3(mk3(x, y, z));
+        if (!same_bits(r.x, want) || !same_bits(r.y, 1.0f / y) || !same_bits(r.z, 1.0f / z)) bad3++;
+    }
+    atomicAdd(&out[0], n); atomicAdd(&out[1], bad1); atomicAdd(&out[2], bad2); atomicAdd(&out[3], bad3);
+}
+} // namespace crt
+extern "C" hipError_t crt_launch_check_reciprocals(unsigned long long* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(crt::check_reciprocals_kernel, dim3(4096), dim3(256), 0, stream, out);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                         uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
                                         uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, uint32_t narrowTiles, uint32_t narrowLanes, hipStream_t stream)

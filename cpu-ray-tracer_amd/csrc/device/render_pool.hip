@@ -126,9 +126,9 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
         f3 D = v, rD = v; Hit nh; nh.t = 1e34f; nh.u = 0; nh.v = 0; nh.objIdx = -1; nh.triIdx = -1;
         uint32_t ncur = kRefDone, pend = 0u;
         if (act) {
-            const float inv = 1.0f / __builtin_sqrtf(dot3(v, v));               // normalize(): v * (1 / sqrtf(dot(v, v)))
+            const float inv = rcp_exact(__builtin_sqrtf(dot3(v, v)));           // normalize(): v * (1 / sqrtf(dot(v, v)))
             D = norm ? v * inv : v;
-            rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
+            rD = rcp_exact3(D);
             cn.rays++;
             hit_light_floor(sc, O, D, nh);
             if (sc.rootIsPair) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
                         pre = medium * brdf * 2.0f * CRT_PI;                       // ... * dot(R, N) once R is normalised
                     }
                     // normalize(R) of the diffuse branch; the bounce's throughput factor and the new origin use the normalised direction
-                    const float inv = 1.0f / __builtin_sqrtf(dot3(v, v));
+                    const float inv = rcp_exact(__builtin_sqrtf(dot3(v, v)));
                     const f3 nv = norm ? v * inv : v;
                     v = nv;
                     const f3 factor = diffuse ? pre * dot3(nv, N) : pre;
