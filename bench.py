@@ -199,7 +199,7 @@ def main():
     # latency of ONE step on its own (submit, wait), next to the job throughput: the literal "one WxH / SPP-spp render"
     lat = []
     if not args.no_single_render:
-        for i in range(5):                          # (the back end times its latency mode on the first two single-window launches and keeps the faster)
+        for i in range(14):                         # (the back end tunes its latency mode over the first 8 single-window launches: tile costs -> block tables, keeps the fastest)
             ctx.clear(); ctx.sync()
             t1 = time.perf_counter()
             ctx.render(1, SPP, 1)
@@ -249,7 +249,7 @@ def main():
                 valu_instrs = int(pw["valu_wave_instructions"] * windows_per_launch)
         except Exception:
             traffic = valu_instrs = pmc = None
-    single_ms = sorted(lat)[len(lat) // 2] if lat else None
+    single_ms = sorted(lat[-5:])[2] if lat else None
     out = {
         "metric": "Mrays/sec (primary+secondary), %dx%d %dspp path trace — pipelined throughput over %d consecutive %d-spp windows of one progressive render (single_render = one such render alone)" % (W, H, SPP, args.steps, SPP),
         "value": round(rays / elapsed / 1e6, 2),
@@ -269,8 +269,8 @@ def main():
                    "collective": None if world == 1 else collective["used"], "rccl_ranks": None if dist is None else dist.get_world_size(), "backend": None if dist is None else dist.get_backend(),
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
                    "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},
-        "single_render": None if not single_ms else {"ms": round(single_ms, 3), "mrays_s": round(counts["rays"] / single_ms / 1e3, 1),
-                                                     "what": "ONE %dx%d / %d-spp render on an idle GPU: clear, crt_render(1, %d, 1), sync (median of 5); it ends on its most expensive tile" % (W, H, SPP, SPP)},
+        "single_render": None if not single_ms else {"ms": round(single_ms, 3), "mrays_s": round(counts["rays"] / single_ms / 1e3, 1), "first_ms": round(lat[0], 3), "untuned_ms": round(lat[1], 3),
+                                                     "what": "ONE %dx%d / %d-spp render on an idle GPU: clear, crt_render(1, %d, 1), sync (14 renders; the first 9 let the back end's latency mode measure the tiles and settle, `ms` = median of the last 5, `first_ms` / `untuned_ms` = renders 1 and 2: one wavefront per tile while the tile costs are measured)" % (W, H, SPP, SPP)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "hbm_actual_frac": None if not traffic or job_launch_ms <= 0 else round(traffic / (job_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

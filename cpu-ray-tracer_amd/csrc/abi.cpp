@@ -14,9 +14,10 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <algorithm>
 #include <vector>
 
-extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
 extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
@@ -84,10 +85,19 @@ struct crt_ctx {
     hipEvent_t sceneReady = nullptr;      // recorded behind the last in-place scene update; render launches wait for it on their stream
     crt::AltAccelDev alt{}; bool haveKd = false, haveGrid = false; std::vector<void*> altAllocs[2]; void* altTris = nullptr; uint32_t altTriCount = 0;   // KD-tree [0] / grid [1] buffers
     void* dQueryRays = nullptr; void* dQueryHits = nullptr; size_t queryCap = 0;      // crt_find_nearest staging (rays)
-    // ... chosen by measurement: the first single-window launch after a scene / camera change runs wide, the second narrow, later ones whichever was faster
-    // (HIP event durations of the launches themselves; identical pixels either way)
-    double tuneMs[2] = {0, 0}; int tuneCount[2] = {0, 0};
-    uint32_t narrowTiles = 0, narrowLanes = 8;   // latency mode of single-window launches: the first narrowTiles tiles of the dispatch order (inside the meshes' screen rectangle) run as 64 / narrowLanes narrow wavefronts
+    // Latency mode of single-window launches (render_tiles_kernel's block table), driven by measurement — see next_block_table.  Stage 0 = one wavefront per tile;
+    // stages 1 .. kLatStages = block tables, each built from the tile costs measured under the best stage so far; afterwards the fastest stage is used
+    // (HIP event durations of the launches themselves; identical pixels whatever the table).
+    static constexpr int kLatStages = 6;       // (the bunny settles by stage 3, the two-level scene still gains at 5; bolder aims do not get lower: DESIGN.md §5)
+    double tuneMs[kLatStages + 1] = {}; int tuneCount[kLatStages + 1] = {};
+    int latStage = 0;              // stage of the table on the device (0: none yet)
+    int latBest = 0;               // fastest stage so far
+    bool latDone = false;          // all stages measured, the fastest one's table is (being) installed
+    bool latWarm = false;          // stage 0 has been measured once already (the first launch after an upload runs cold: it is measured twice)
+    std::vector<uint8_t> latL[kLatStages + 1];          // lanes per wavefront of every tile, per stage ([0]: all 64)
+    std::vector<uint32_t> latCost[kLatStages + 1];      // measured tile costs, per stage
+    uint32_t* dTileCost = nullptr; uint32_t* hTileCost = nullptr; hipEvent_t costCopied = nullptr; bool costPending = false; int costStage = 0;
+    uint32_t* dBlockDesc = nullptr; uint32_t* hBlockDesc = nullptr; uint32_t nBlocks = 0, descCap = 0; hipEvent_t descReady = nullptr;
     uint64_t poolMinWaves = 65000; // launches of fewer (tile, 64-frame window) pairs run render_tiles_kernel: see crt_render
     bool usePool = true;          // render_pool_kernel (stream pool); CRT_RENDER_KERNEL=tiles selects render_tiles_kernel (one stream per lane)
     uint32_t ldsBytes = 0;
@@ -264,6 +274,12 @@ void crt_destroy(crt_ctx* c)
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->dTileClocks) (void)hipFree(c->dTileClocks);
     if (c->dTileOrder) (void)hipFree(c->dTileOrder);
+    if (c->dTileCost) (void)hipFree(c->dTileCost);
+    if (c->hTileCost) (void)hipHostFree(c->hTileCost);
+    if (c->costCopied) (void)hipEventDestroy(c->costCopied);
+    if (c->dBlockDesc) (void)hipFree(c->dBlockDesc);
+    if (c->hBlockDesc) (void)hipHostFree(c->hBlockDesc);
+    if (c->descReady) (void)hipEventDestroy(c->descReady);
     if (c->dQueryRays) (void)hipFree(c->dQueryRays);
     if (c->dQueryHits) (void)hipFree(c->dQueryHits);
     for (int k = 0; k < 2; k++) { if (c->hTileOrder[k]) (void)hipHostFree(c->hTileOrder[k]); if (c->orderCopied[k]) (void)hipEventDestroy(c->orderCopied[k]); }
@@ -672,7 +688,7 @@ int crt_set_camera(crt_ctx* c, const float camPos[3], const float tl[3], const f
 }
 
 // Tiles (local indices 0..tileCount) ordered so that those inside the screen-space bounding rectangle of the meshes' world box come first
-// (they are also the `narrowTiles` set of the latency mode).  Pure scheduling heuristic: the projection uses the pin-hole camera of crt_set_camera in double precision and is conservative on failure
+// (the stream-pool kernel and wide launches dispatch in this order).  Pure scheduling heuristic: the projection uses the pin-hole camera of crt_set_camera in double precision and is conservative on failure
 // (a corner behind the eye makes every tile a candidate).
 static int update_tile_order(crt_ctx* c)
 {
@@ -704,7 +720,7 @@ static int update_tile_order(crt_ctx* c)
     float world[24];
     for (int i = 0; i < 8; i++) { world[3 * i] = (i & 1) ? c->meshHi[0] : c->meshLo[0]; world[3 * i + 1] = (i & 2) ? c->meshHi[1] : c->meshLo[1]; world[3 * i + 2] = (i & 4) ? c->meshHi[2] : c->meshLo[2]; }
     int wr[4] = {0, c->tilesX - 1, 0, c->tilesY - 1};
-    const bool all = !rect_of(world, wr);
+    (void)rect_of(world, wr);                                     // on failure wr stays the whole image
     std::vector<uint32_t> first, second, rest;
     for (uint32_t i = 0; i < c->tileCount; i++) {
         const uint32_t tile = c->tileFirst + i * c->tileStride;
@@ -712,12 +728,9 @@ static int update_tile_order(crt_ctx* c)
         const bool inRect = tx >= wr[0] && tx <= wr[1] && ty >= wr[2] && ty <= wr[3];
         if (inRect) first.push_back(i); else rest.push_back(i);
     }
-    // latency mode (single-window launches): the tiles of the rectangle MAY run as narrow wavefronts; whether that pays depends on the scene — measured
-    // (tools/latency_probe.py, one 64-spp render, 8 lanes): bunny 1280x720 32.6 -> 27.7 ms (16 lanes 30.3, 4 lanes 34.8; every tile narrow 40.0), TLAS scene
-    // 58.7 -> 51.2 ms, watch-tower 1920x1080 79.8 -> 109.7 ms — so crt_render decides by timing both on the first two launches (see tuneMs)
-    c->narrowTiles = all ? 0u : (uint32_t)first.size();
-    c->tuneCount[0] = c->tuneCount[1] = 0;
-    if (const char* e = getenv("CRT_NARROW_LANES")) { c->narrowLanes = (uint32_t)atoi(e); if (c->narrowLanes == 0u) c->narrowTiles = 0u; }
+    // a new camera / scene: the latency mode measures again (see next_block_table)
+    for (int k = 0; k <= crt_ctx::kLatStages; k++) { c->tuneCount[k] = 0; c->tuneMs[k] = 0; }
+    c->latStage = 0; c->latBest = 0; c->latDone = false; c->latWarm = false; c->costPending = false;
     first.insert(first.end(), rest.begin(), rest.end());
     // No host synchronisation: the copy runs on the main stream, which is ordered behind every render launch submitted so far (it waits for
     // each launch's end event before that launch's accumulate), so the previous order is no longer read when it is overwritten; later
@@ -740,6 +753,101 @@ static int update_tile_order(crt_ctx* c)
 // A launch's region = [samples of all its windows][scratch of all its windows].
 static size_t sample_bytes_per_window(const crt_ctx* c, uint32_t passes) { return (size_t)c->tileCount * 256u * 64u * passes * 16u; }
 static size_t window_bytes(const crt_ctx* c, uint32_t passes) { return sample_bytes_per_window(c, passes) + (c->usePool ? crt_pool_scratch_bytes_per_window(c->tileCount) : 0); }
+
+// Latency mode: block tables of single-window launches from measured tile costs (100 MHz ticks of a tile's slowest wavefront).  A launch ends on its slowest
+// wavefront, and a wavefront's speed is set by how many phases (NODE / TRI / SHADE) its lanes populate per trip, not by its lane count — so a tile given to
+// 64 / L wavefronts of L lanes runs its streams' serial chains faster, at the price of 64 / L times the instruction issue.  Measured on the bunny's heaviest
+// tiles (tools/latency_probe.py, everything else one wave per tile): time(L) / time(64) = 0.93 (32), 0.88 (16), 0.79 (8), 0.69 (4), 0.57 (2), 0.48 (1) — but the
+// ratio differs from tile to tile (phase mix) and shrinks when the extra wavefronts compete for instruction issue, so the tables are found by FEEDBACK: each
+// stage starts from the fastest stage so far (its lanes per tile and the costs measured under it), aims at `aim` x that stage's slowest tile, narrows every tile
+// the model says would miss the aim and widens every tile that would make it with wavefronts twice as wide; crt_render times each stage and keeps the fastest.
+// CRT_LAT_POLICY="share:lanes,.." replaces stage 1 by fixed steps (tiles costing >= share x the slowest get `lanes`) and stops there.
+static const uint32_t kLatLanes[7] = {64u, 32u, 16u, 8u, 4u, 2u, 1u};
+static const double kLatG[7] = {1.0, 0.93, 0.88, 0.79, 0.69, 0.57, 0.48};
+static int lat_index(uint32_t L) { int k = 0; while (k < 6 && kLatLanes[k] != L) k++; return k; }
+
+static int upload_block_table(crt_ctx* c, const std::vector<uint8_t>& lanes, const std::vector<uint32_t>& cost)
+{
+    const uint32_t n = c->tileCount;
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });      // issued most expensive tile first
+    std::vector<uint32_t> table; table.reserve((size_t)n * 2);
+    for (uint32_t r = 0; r < n; r++) {
+        const uint32_t tl = order[r], L = lanes[tl];
+        for (uint32_t base = 0; base < 64u; base += L) table.push_back(tl | (base << 20) | ((L - 1u) << 26));
+    }
+    if (table.size() > 0x7fffffffull) return c->fail(CRT_ERR_INVALID, "block table too large");
+    if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] latency table: %zu wavefronts for %u tiles (slowest tile of the base stage %.2f ms)\n", table.size(), n, n ? cost[order[0]] * 1e-5 : 0.0);
+    if (c->descCap < table.size()) {
+        if (c->dBlockDesc) (void)hipFree(c->dBlockDesc);
+        if (c->hBlockDesc) (void)hipHostFree(c->hBlockDesc);
+        c->dBlockDesc = nullptr; c->hBlockDesc = nullptr; c->descCap = 0;
+        const size_t cap = table.size() + table.size() / 2;
+        HIPCK(c, hipMalloc((void**)&c->dBlockDesc, cap * 4));
+        HIPCK(c, hipHostMalloc((void**)&c->hBlockDesc, cap * 4, hipHostMallocDefault));
+        c->descCap = (uint32_t)cap;
+    } else if (c->descReady) HIPCK(c, hipEventSynchronize(c->descReady));     // the staging buffer's previous copy (long done)
+    if (!c->descReady) HIPCK(c, hipEventCreateWithFlags(&c->descReady, hipEventDisableTiming));
+    memcpy(c->hBlockDesc, table.data(), table.size() * 4);
+    // on the main stream: ordered behind every launch submitted so far (each launch's accumulate waits for it there), so the previous table is no longer read
+    HIPCK(c, hipMemcpyAsync(c->dBlockDesc, c->hBlockDesc, table.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipEventRecord(c->descReady, c->stream));
+    c->nBlocks = (uint32_t)table.size();
+    return 0;
+}
+
+// the costs of stage `c->costStage` have arrived in hTileCost: remember them, then build and install the next stage's table (or, after the last stage, the fastest one's)
+static int next_block_table(crt_ctx* c)
+{
+    const uint32_t n = c->tileCount; const int K = crt_ctx::kLatStages;
+    const int s = c->costStage;
+    if (s == 0 && !c->latWarm) { c->latWarm = true; return 0; }          // measure the one-wave launch once more, warm
+    c->latCost[s].assign(c->hTileCost, c->hTileCost + n);
+    if (s == 0) c->latL[0].assign(n, 64);
+    if (c->tuneCount[s] && (c->latBest == s || c->tuneMs[s] < c->tuneMs[c->latBest])) c->latBest = s;
+    bool last = s >= K;
+    std::vector<std::pair<double, uint32_t>> steps;
+    if (const char* e = getenv("CRT_LAT_POLICY")) {
+        for (const char* p = e; *p;) {
+            char* q = nullptr; const double sh = strtod(p, &q); if (q == p || *q != ':') break;
+            const long L = strtol(q + 1, &q, 10); if (L < 1 || L > 64 || (64 % L) != 0) break;
+            steps.push_back({sh, (uint32_t)L});
+            p = (*q == ',') ? q + 1 : q; if (*q != ',') break;
+        }
+        if (s >= 1) last = true;
+    }
+    if (last) {                                                           // install the fastest stage's table (stage 0 needs none)
+        c->latDone = true;
+        if (getenv("CRT_LAT_FORCE")) c->latBest = s;                       // diagnostics: keep the last table whatever its time
+        if (getenv("CRT_LAT_VERBOSE")) { fprintf(stderr, "[crt] latency stages:"); for (int k = 0; k <= K; k++) if (c->tuneCount[k]) fprintf(stderr, " %d: %.2f ms", k, c->tuneMs[k]); fprintf(stderr, " -> %d\n", c->latBest); }
+        if (c->latBest != 0 && c->latBest != c->latStage) { const int b = c->latBest; const int r = upload_block_table(c, c->latL[b], c->latCost[b]); if (r) return r; }
+        c->latStage = c->latBest;
+        return 0;
+    }
+    const int b = c->latBest;                                              // base: the fastest stage so far
+    const std::vector<uint8_t>& baseL = c->latL[b]; const std::vector<uint32_t>& baseC = c->latCost[b];
+    uint32_t top = 0; for (uint32_t i = 0; i < n; i++) top = baseC[i] > top ? baseC[i] : top;
+    std::vector<uint8_t>& L = c->latL[s + 1]; L = baseL;
+    if (!steps.empty()) {
+        for (uint32_t i = 0; i < n; i++)
+            for (const auto& st : steps) if (top > 0 && (double)baseC[i] >= st.first * (double)top) { L[i] = (uint8_t)st.second; break; }
+    } else {
+        double aim = s == 0 ? 0.64 : 0.92;
+        if (const char* e = getenv("CRT_LAT_AIM")) { const double v = atof(e); if (s > 0 && v > 0) aim = v; }
+        const double T = aim * (double)top;
+        for (uint32_t i = 0; i < n; i++) {
+            int k = lat_index(baseL[i]); const double unit = (double)baseC[i] / kLatG[k];     // the model's one-wave cost of this tile
+            while (k < 6 && unit * kLatG[k] > T) k++;                                          // narrower until the model meets the aim
+            while (k > 0 && unit * kLatG[k - 1] <= 0.9 * T) k--;                                // wider while twice as wide still makes it comfortably
+            L[i] = (uint8_t)kLatLanes[k];
+        }
+    }
+    const int r = upload_block_table(c, L, baseC);
+    if (r) return r;
+    c->latStage = s + 1;
+    return 0;
+}
 
 // Timing pairs of launches that have completed are folded into running totals and recycled, so a host that renders forever and never
 // asks for the timing (an interactive Tick loop) keeps a bounded number of HIP events alive.
@@ -883,13 +991,24 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         harvest_tuning(c);
         fold_completed(c, c->evRender, &c->foldedRenderMs, &c->foldedLaunches); fold_completed(c, c->evAcc, &c->foldedAccMs, nullptr);
         if ((r = take_event(c, c->evRender, &ev))) return r;
-        // latency mode of a single-window launch (render_tiles_kernel): wide, or narrow wavefronts for the tiles of the meshes' rectangle
-        uint32_t narrow = 0;
-        if (nf <= 64u && nf > c->narrowLanes && c->narrowTiles != 0u && !c->cfg.collectStats) {
-            int mode = c->tuneCount[0] == 0 ? 0 : (c->tuneCount[1] == 0 ? 1 : (c->tuneMs[1] < c->tuneMs[0] ? 1 : 0));
-            if (const char* e = getenv("CRT_NARROW_FORCE")) mode = atoi(e) ? 1 : 0;
-            narrow = mode ? c->narrowTiles : 0u;
-            c->evRender.back().mode = mode;
+        // latency mode of a single-window launch (render_tiles_kernel): one wavefront per tile, or the current block table (see next_block_table)
+        const uint32_t* blockDesc = nullptr; uint32_t nBlocks = 0; bool wantCost = false;
+        if (nf <= 64u && nf >= 8u && !c->cfg.collectStats && !getenv("CRT_LAT_OFF")) {
+            if (c->costPending && hipEventQuery(c->costCopied) == hipSuccess) { c->costPending = false; harvest_tuning(c); if ((r = next_block_table(c))) return r; }
+            const int stage = c->latStage;
+            if (stage) { blockDesc = c->dBlockDesc; nBlocks = c->nBlocks; HIPCK(c, hipStreamWaitEvent(st, c->descReady, 0)); }
+            wantCost = (!c->latDone && !c->costPending) || (c->latDone && getenv("CRT_LAT_RECORD"));      // (the latter: diagnostics, crt_debug_tile_costs)
+            c->evRender.back().mode = c->latDone ? -1 : stage;
+            if (wantCost && !c->latDone) c->costStage = stage;
+        }
+        if (wantCost) {
+            if (!c->dTileCost) {
+                HIPCK(c, hipMalloc((void**)&c->dTileCost, (size_t)c->tileCount * 4));
+                HIPCK(c, hipHostMalloc((void**)&c->hTileCost, (size_t)c->tileCount * 4, hipHostMallocDefault));
+                HIPCK(c, hipEventCreateWithFlags(&c->costCopied, hipEventDisableTiming));
+            }
+            else HIPCK(c, hipStreamWaitEvent(st, c->costCopied, 0));          // behind an earlier measurement (possibly on another stream) that a camera change abandoned
+            HIPCK(c, hipMemsetAsync(c->dTileCost, 0, (size_t)c->tileCount * 4, st));
         }
         HIPCK(c, hipEventRecord(ev.a, st));
         // Which render kernel: the stream pool executes a third fewer instructions per sample, but its wavefronts own 128 streams for 64 lanes, so the most
@@ -905,7 +1024,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
                                         c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->cfg.collectStats, st);
         else
             le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, narrow, c->narrowLanes, st);
+                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, blockDesc, nBlocks, wantCost ? c->dTileCost : nullptr, st);
         if (le != hipSuccess) {
             // a launch that failed has rendered nothing: take its timing pair back (a half-recorded pair would poison crt_get_timing), leave the accumulator
             // and the region bookkeeping untouched — the frames before it are in, this one and the rest are not — and report
@@ -914,6 +1033,11 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         }
         if (pool) c->poolLaunches++;
         HIPCK(c, hipEventRecord(ev.b, st));
+        if (wantCost && !pool && !c->latDone) {                                                // the tile costs travel to the host behind the launch; looked at by a later crt_render
+            HIPCK(c, hipMemcpyAsync(c->hTileCost, c->dTileCost, (size_t)c->tileCount * 4, hipMemcpyDeviceToHost, st));
+            HIPCK(c, hipEventRecord(c->costCopied, st));
+            c->costPending = true;
+        }
         // ordered accumulation on the main stream (frame order = launch order), behind this launch
         HIPCK(c, hipStreamWaitEvent(c->stream, ev.b, 0));
         if ((r = take_event(c, c->evAcc, &ev))) return r;
@@ -1164,6 +1288,16 @@ extern "C" int crt_debug_check_reciprocals(crt_ctx* c, uint64_t* out)
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     HIPCK(c, e);
+    return CRT_OK;
+}
+
+// diagnostics (tools/latency_probe.py): the tile costs the last recording single-window launch left on the device (100 MHz ticks, longest wavefront per tile)
+extern "C" int crt_debug_tile_costs(crt_ctx* c, uint32_t* out)
+{
+    if (!c || !out || !c->dTileCost) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipDeviceSynchronize());
+    HIPCK(c, hipMemcpy(out, c->dTileCost, (size_t)c->tileCount * 4, hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

@@ -67,11 +67,11 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                                                            const uint32_t* __restrict__ tileOrder,
                                                            uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                            uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t windows,
-                                                           uint32_t narrowTiles, uint32_t narrowLanes)
+                                                           const uint32_t* __restrict__ blockDesc, uint32_t* __restrict__ tileCost)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    const unsigned long long clk0 = COUNT ? wall_clock64() : 0ull;
+    const unsigned long long clk0 = (COUNT || tileCost) ? wall_clock64() : 0ull;
     // block -> tile.  The kernel's duration is set by its most expensive tiles (one serial RNG stream per lane), so the host
     // lists the tiles whose pixels can see the meshes FIRST (tileOrder): the dispatcher starts them first and they are dealt
     // round-robin over the 8 XCDs / 256 CUs instead of piling up on the XCDs that own the image rows of the model.  The
@@ -81,21 +81,19 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     // all windows of the expensive tiles are dispatched first and the cheap tiles fill the machine behind them, so a long job is
     // one grid whose duration is total work / machine throughput instead of a sequence of launches that each end on their
     // heaviest tile.
-    // Latency mode (a launch of ONE window, narrowTiles > 0): the launch ends on its most expensive tile — one serial stream per lane, and every
-    // trip of that wave pays for all the phases its 64 lanes populate.  The first `narrowTiles` tiles of the order (those that can see the meshes)
-    // are therefore rendered by 64 / narrowLanes wavefronts of narrowLanes lanes each: fewer phases are populated per trip, so each stream's
-    // serial chain advances faster, and the idle part of the chip takes the extra wavefronts.  laneBase = first frame of this wavefront.
-    uint32_t rank, win = 0u, laneBase = 0u;
-    if (narrowTiles != 0u) {
-        const uint32_t subs = 64u / narrowLanes, nb = narrowTiles * subs;
-        if (blockIdx.x < nb) { rank = blockIdx.x / subs; laneBase = (blockIdx.x - rank * subs) * narrowLanes; }
-        else rank = narrowTiles + (blockIdx.x - nb);
-    } else { rank = blockIdx.x / windows; win = blockIdx.x - rank * windows; }
+    // Latency mode (a launch of ONE window with a block table): the launch ends on its most expensive tile — one serial stream per lane, and every
+    // trip of that wave pays for all the phases its 64 lanes populate (NODE and TRI nearly always; a lone wave issues one instruction per 6 - 9 cycles
+    // whatever its lane count, tools/microbench/lone_wave.hip).  The host therefore measures the tiles (tileCost, below) and gives the expensive ones
+    // to SEVERAL wavefronts of fewer lanes each: fewer phases are populated per trip, so each stream's serial chain advances faster, and the idle part of the
+    // chip takes the extra wavefronts.  blockDesc[block] = local tile index | first frame << 20 | (lanes - 1) << 26; blocks are listed most expensive tile first.
+    uint32_t rank, win = 0u, laneBase = 0u, myLanes = 64u;
+    if (blockDesc) { const uint32_t d = blockDesc[blockIdx.x]; rank = d & 0xfffffu; laneBase = (d >> 20) & 63u; myLanes = (d >> 26) + 1u; }
+    else { rank = blockIdx.x / windows; win = blockIdx.x - rank * windows; }
     if (rank >= tileCount) return;
-    const uint32_t tl = tileOrder ? tileOrder[rank] : rank;
+    const uint32_t tl = blockDesc ? rank : (tileOrder ? tileOrder[rank] : rank);       // (a block table names local tile indices itself)
     sppFirst += win * 64u * passes;
     frames = (frames - win * 64u < 64u) ? frames - win * 64u : 64u;               // frames of THIS window (the last one may be partial)
-    if (narrowTiles != 0u && blockIdx.x < narrowTiles * (64u / narrowLanes)) frames = frames > laneBase ? ((frames - laneBase < narrowLanes) ? frames - laneBase : narrowLanes) : 0u;
+    if (blockDesc) frames = frames > laneBase ? ((frames - laneBase < myLanes) ? frames - laneBase : myLanes) : 0u;
     slab += (size_t)win * ((size_t)tileCount * 256u * 64u * passes);              // this window's region of the sample slab
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
@@ -104,8 +102,8 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 
     Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
     uint32_t trips = 0;
-    const bool narrowWave = narrowTiles != 0u && blockIdx.x < narrowTiles * (64u / narrowLanes);
-    const int shadeBatch = narrowWave ? (int)((narrowLanes * 3u + 7u) / 8u) : (windows >= 8u ? CRT_SHADE_BATCH_JOB : CRT_SHADE_BATCH);   // (24 of 64 lanes, scaled to a narrow wavefront)
+    const bool narrowWave = myLanes < 64u;
+    const int shadeBatch = narrowWave ? (int)((myLanes * 3u + 7u) / 8u) : (windows >= 8u ? CRT_SHADE_BATCH_JOB : CRT_SHADE_BATCH);   // (24 of 64 lanes, scaled to a narrow wavefront)
 #ifdef CRT_STAMPS
     // diagnostic build (-DCRT_STAMPS): shader-clock time per phase of this wave; never compiled into the product
     unsigned long long stT[6] = {0, 0, 0, 0, 0, 0}; uint32_t stN[4] = {0, 0, 0, 0}; uint32_t stL[4] = {0, 0, 0, 0};
@@ -113,7 +111,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 #else
 #define CRT_STAMP(var)
 #endif
-    const uint32_t S = frames * passes;
     const uint32_t items = 256u * passes;                                     // (pixel, pass) pairs in stream order
     const f3 camPos = mk3(sc.camPos[0], sc.camPos[1], sc.camPos[2]);
     const f3 TL = mk3(sc.topLeft[0], sc.topLeft[1], sc.topLeft[2]);
@@ -463,6 +460,8 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     }
 #undef CRT_TOP
 
+    // what this tile cost (100 MHz wall clock ticks; the longest of its wavefronts): the host's latency mode sizes the next launch's wavefronts with it
+    if (tileCost && lane == 0) atomicMax(&tileCost[tl], (uint32_t)(wall_clock64() - clk0));
     if (COUNT && tileClocks && lane == 0 && windows == 1u) {                 // instrumentation build only: per-tile wall time + loop trips
         tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
         tileClocks[2 * tl + 1] = trips;
@@ -836,17 +835,18 @@ extern "C" hipError_t crt_launch_check_reciprocals(unsigned long long* out, hipS
     return hipGetLastError();
 }
 
+// blockDesc / nBlocks: latency mode (see the kernel) for a launch of one window, else nullptr / 0; tileCost: nullptr or one uint32 per tile, atomicMax'ed
 extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                         uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
-                                        uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, uint32_t narrowTiles, uint32_t narrowLanes, hipStream_t stream)
+                                        uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, const uint32_t* blockDesc, uint32_t nBlocks, uint32_t* tileCost, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
     const uint32_t windows = (frames + 63u) / 64u;                      // one 64-lane wavefront per (tile, 64-frame window)
     if ((unsigned long long)tileCount * windows > 0x7fffffffull) return hipErrorInvalidValue;
-    if (windows != 1u || narrowLanes == 0u || narrowLanes >= 64u || (64u % narrowLanes) != 0u || frames <= narrowLanes || collectStats) narrowTiles = 0u;   // latency mode: single-window launches of more frames than one narrow wavefront holds
-    if (narrowTiles > tileCount) narrowTiles = tileCount;
-    dim3 grid(narrowTiles ? narrowTiles * (64u / narrowLanes) + (tileCount - narrowTiles) : tileCount * windows), block(64);
-#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows, narrowTiles, narrowLanes)
+    if (windows != 1u || collectStats || nBlocks == 0u) blockDesc = nullptr;      // latency mode: single-window launches only
+    if (blockDesc && tileCount > 0x100000u) return hipErrorInvalidValue;
+    dim3 grid(blockDesc ? nBlocks : tileCount * windows), block(64);
+#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows, blockDesc, tileCost)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH(0, true); else CRT_LAUNCH(0, false); }
     else { if (collectStats) CRT_LAUNCH(1, true); else CRT_LAUNCH(1, false); }
 #undef CRT_LAUNCH
