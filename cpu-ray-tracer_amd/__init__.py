@@ -65,7 +65,7 @@ class CountersS(C.Structure):
 
 
 class TimingS(C.Structure):
-    _fields_ = [("render_kernel_ms", C.c_float), ("resolve_kernel_ms", C.c_float), ("render_launches", C.c_uint32), ("pool_launches", C.c_uint32)]
+    _fields_ = [("render_kernel_ms", C.c_float), ("resolve_kernel_ms", C.c_float), ("render_launches", C.c_uint32), ("pool_launches", C.c_uint32), ("split_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 TRI_DTYPE = np.dtype([("vertex0", "<f4", 3), ("vertex1", "<f4", 3), ("vertex2", "<f4", 3),
@@ -280,7 +280,7 @@ class Context:
     def timing(self):
         t = TimingS()
         self._ck(self.L.crt_get_timing(self.h, C.byref(t)))
-        return dict(render_kernel_ms=t.render_kernel_ms, resolve_kernel_ms=t.resolve_kernel_ms, render_launches=t.render_launches, pool_launches=t.pool_launches)
+        return dict(render_kernel_ms=t.render_kernel_ms, resolve_kernel_ms=t.resolve_kernel_ms, render_launches=t.render_launches, pool_launches=t.pool_launches, split_launches=t.split_launches)
 
     def tile_clocks(self, tile_count):
         a = np.zeros((tile_count, 2), np.uint64)

@@ -17,9 +17,9 @@
 #include <algorithm>
 #include <vector>
 
-extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
+extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, const uint32_t*, uint32_t, uint32_t*, uint32_t, hipStream_t);
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
-extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t*, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_whitted(const crt::Scene*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
@@ -98,6 +98,13 @@ struct crt_ctx {
     std::vector<uint32_t> latCost[kLatStages + 1];      // measured tile costs, per stage
     uint32_t* dTileCost = nullptr; uint32_t* hTileCost = nullptr; hipEvent_t costCopied = nullptr; bool costPending = false; int costStage = 0;
     uint32_t* dBlockDesc = nullptr; uint32_t* hBlockDesc = nullptr; uint32_t nBlocks = 0, descCap = 0; hipEvent_t descReady = nullptr;
+    // Jobs (launches of several windows): what each tile costs is measured once per camera / scene by the first job launch (every wavefront's duration, scaled to
+    // 64 streams); later launches dispatch the tiles most expensive first and SPLIT: see split_point
+    uint32_t* dJobCost = nullptr; uint32_t* hJobCost = nullptr; hipEvent_t jobCostCopied = nullptr; bool jobCostPending = false, jobCostValid = false;
+    std::vector<uint32_t> jobCost;          // per local tile, 100 MHz ticks; sorted view = the tile order on the device once jobCostValid
+    std::vector<uint32_t> jobOrder;
+    std::vector<hipEvent_t> splitEvents;    // end events of the second kernel of split launches (recycled round-robin)
+    size_t splitSeq = 0; uint32_t splitLaunches = 0;
     uint64_t poolMinWaves = 65000; // launches of fewer (tile, 64-frame window) pairs run render_tiles_kernel: see crt_render
     bool usePool = true;          // render_pool_kernel (stream pool); CRT_RENDER_KERNEL=tiles selects render_tiles_kernel (one stream per lane)
     uint32_t ldsBytes = 0;
@@ -275,6 +282,10 @@ void crt_destroy(crt_ctx* c)
     if (c->dTileClocks) (void)hipFree(c->dTileClocks);
     if (c->dTileOrder) (void)hipFree(c->dTileOrder);
     if (c->dTileCost) (void)hipFree(c->dTileCost);
+    if (c->dJobCost) (void)hipFree(c->dJobCost);
+    if (c->hJobCost) (void)hipHostFree(c->hJobCost);
+    if (c->jobCostCopied) (void)hipEventDestroy(c->jobCostCopied);
+    for (auto e : c->splitEvents) (void)hipEventDestroy(e);
     if (c->hTileCost) (void)hipHostFree(c->hTileCost);
     if (c->costCopied) (void)hipEventDestroy(c->costCopied);
     if (c->dBlockDesc) (void)hipFree(c->dBlockDesc);
@@ -687,6 +698,24 @@ int crt_set_camera(crt_ctx* c, const float camPos[3], const float tl[3], const f
     return CRT_OK;      // the Scene block travels by value in every launch's kernel arguments
 }
 
+// the dispatch order of the tiles (local indices) to the device.  No host synchronisation: the copy runs on the main stream, which is ordered behind every render
+// launch submitted so far (it waits for each launch's end event before that launch's accumulate), so the previous order is no longer read when it is overwritten;
+// later launches wait for `orderReady` on their own stream.  The staging buffers are pinned and alternate; one is reused only after its own copy.
+static int upload_tile_order(crt_ctx* c, const std::vector<uint32_t>& order)
+{
+    if (!c->dTileOrder) HIPCK(c, hipMalloc((void**)&c->dTileOrder, (size_t)c->tileCount * 4));
+    const int k = c->orderFlip ^= 1;
+    if (!c->hTileOrder[k]) {
+        HIPCK(c, hipHostMalloc((void**)&c->hTileOrder[k], (size_t)c->tileCount * 4, hipHostMallocDefault));
+        HIPCK(c, hipEventCreateWithFlags(&c->orderCopied[k], hipEventDisableTiming));
+    } else HIPCK(c, hipEventSynchronize(c->orderCopied[k]));
+    memcpy(c->hTileOrder[k], order.data(), order.size() * 4);
+    HIPCK(c, hipMemcpyAsync(c->dTileOrder, c->hTileOrder[k], order.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipEventRecord(c->orderCopied[k], c->stream));
+    c->orderReady = c->orderCopied[k];
+    return 0;
+}
+
 // Tiles (local indices 0..tileCount) ordered so that those inside the screen-space bounding rectangle of the meshes' world box come first
 // (the stream-pool kernel and wide launches dispatch in this order).  Pure scheduling heuristic: the projection uses the pin-hole camera of crt_set_camera in double precision and is conservative on failure
 // (a corner behind the eye makes every tile a candidate).
@@ -732,19 +761,8 @@ static int update_tile_order(crt_ctx* c)
     for (int k = 0; k <= crt_ctx::kLatStages; k++) { c->tuneCount[k] = 0; c->tuneMs[k] = 0; }
     c->latStage = 0; c->latBest = 0; c->latDone = false; c->latWarm = false; c->costPending = false;
     first.insert(first.end(), rest.begin(), rest.end());
-    // No host synchronisation: the copy runs on the main stream, which is ordered behind every render launch submitted so far (it waits for
-    // each launch's end event before that launch's accumulate), so the previous order is no longer read when it is overwritten; later
-    // launches wait for `orderReady` on their own stream.  The staging buffers are pinned and alternate; one is reused only after its own copy.
-    if (!c->dTileOrder) HIPCK(c, hipMalloc((void**)&c->dTileOrder, (size_t)c->tileCount * 4));
-    const int k = c->orderFlip ^= 1;
-    if (!c->hTileOrder[k]) {
-        HIPCK(c, hipHostMalloc((void**)&c->hTileOrder[k], (size_t)c->tileCount * 4, hipHostMallocDefault));
-        HIPCK(c, hipEventCreateWithFlags(&c->orderCopied[k], hipEventDisableTiming));
-    } else HIPCK(c, hipEventSynchronize(c->orderCopied[k]));
-    memcpy(c->hTileOrder[k], first.data(), first.size() * 4);
-    HIPCK(c, hipMemcpyAsync(c->dTileOrder, c->hTileOrder[k], first.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipEventRecord(c->orderCopied[k], c->stream));
-    c->orderReady = c->orderCopied[k];
+    c->jobCostValid = false; c->jobCostPending = false;
+    { const int r = upload_tile_order(c, first); if (r) return r; }
     c->orderDirty = false;
     return 0;
 }
@@ -960,6 +978,37 @@ static int take_region(crt_ctx* c, size_t need, hipStream_t st, size_t* offOut)
     }
 }
 
+// A job's tile costs have arrived (hJobCost): dispatch order = most expensive tile first from now on
+static int adopt_job_costs(crt_ctx* c)
+{
+    const uint32_t n = c->tileCount;
+    c->jobCost.assign(c->hJobCost, c->hJobCost + n);
+    c->jobOrder.resize(n);
+    for (uint32_t i = 0; i < n; i++) c->jobOrder[i] = i;
+    std::stable_sort(c->jobOrder.begin(), c->jobOrder.end(), [&](uint32_t a, uint32_t b) { return c->jobCost[a] > c->jobCost[b]; });
+    c->jobCostValid = true;
+    return upload_tile_order(c, c->jobOrder);
+}
+
+// Split point of a pool job of `windows` windows: the stream pool executes a third fewer instructions per sample, but its wavefronts own 128 streams for 64 lanes —
+// the wavefronts of the most expensive tiles run 2.4x as long as a one-stream-per-lane wavefront of the same tile (bunny: 82 ms against 34 ms), and a job that is
+// not many times longer than that ends on them with the chip nearly empty (tools/pool_timeline.py: 20 windows, 4 096 waves in flight until 65 ms, then a tail to
+// 83 ms).  With the tile costs known, the first H tiles of the (cost-sorted) order — those whose pool wavefront would outlast 0.9 x the job's ideal length
+// (total wave time / wavefronts in flight) — are rendered by a concurrent render_tiles_kernel launch instead (all windows, dispatched first), the rest by the pool.
+static uint32_t split_point(const crt_ctx* c, uint32_t windows)
+{
+    if (!c->jobCostValid || windows < 2u || c->cfg.collectStats || c->streams.size() < 2 || getenv("CRT_SPLIT_OFF")) return 0u;
+    if (const char* e = getenv("CRT_SPLIT_FORCE")) { const uint32_t h = (uint32_t)atoi(e); return h < c->tileCount ? h : c->tileCount - 1u; }      // tests
+    double poolLong = 2.4, slack = 1.0;
+    if (const char* e = getenv("CRT_SPLIT_SLACK")) slack = atof(e);
+    double sum = 0; for (uint32_t v : c->jobCost) sum += (double)v;
+    const double ideal = 0.5 * poolLong * (double)windows * sum / 4096.0;       // every tile in the pool: windows / 2 wavefronts of 2.4 x cost each, 4 096 in flight
+    uint32_t H = 0;
+    while (H < c->tileCount / 4u && poolLong * (double)c->jobCost[c->jobOrder[H]] > slack * ideal) H++;
+    if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] job of %u windows: ideal %.1f ms, most expensive tile %.2f ms (pool wavefront %.1f ms), %u tiles to render_tiles_kernel\n", windows, ideal * 1e-5, c->jobCost[c->jobOrder[0]] * 1e-5, poolLong * c->jobCost[c->jobOrder[0]] * 1e-5, H);
+    return H;
+}
+
 int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
 {
     if (!c) return CRT_ERR_INVALID;
@@ -1010,21 +1059,59 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
             else HIPCK(c, hipStreamWaitEvent(st, c->costCopied, 0));          // behind an earlier measurement (possibly on another stream) that a camera change abandoned
             HIPCK(c, hipMemsetAsync(c->dTileCost, 0, (size_t)c->tileCount * 4, st));
         }
+        // jobs: measure the tile costs once per camera / scene (first job launch), adopt them when they have arrived
+        bool wantJobCost = false;
+        if (nf > 64u && !c->cfg.collectStats) {
+            if (c->jobCostPending && hipEventQuery(c->jobCostCopied) == hipSuccess) { c->jobCostPending = false; if ((r = adopt_job_costs(c))) return r; HIPCK(c, hipStreamWaitEvent(st, c->orderReady, 0)); }
+            wantJobCost = !c->jobCostValid && !c->jobCostPending && nf >= 128u;       // (the pool records full 128-stream wavefronts only)
+            if (wantJobCost) {
+                if (!c->dJobCost) {
+                    HIPCK(c, hipMalloc((void**)&c->dJobCost, (size_t)c->tileCount * 4));
+                    HIPCK(c, hipHostMalloc((void**)&c->hJobCost, (size_t)c->tileCount * 4, hipHostMallocDefault));
+                    HIPCK(c, hipEventCreateWithFlags(&c->jobCostCopied, hipEventDisableTiming));
+                } else HIPCK(c, hipStreamWaitEvent(st, c->jobCostCopied, 0));      // behind an earlier measurement that a camera change abandoned
+                HIPCK(c, hipMemsetAsync(c->dJobCost, 0, (size_t)c->tileCount * 4, st));
+            }
+        }
         HIPCK(c, hipEventRecord(ev.a, st));
         // Which render kernel: the stream pool executes a third fewer instructions per sample, but its wavefronts own 128 streams for 64 lanes, so the most
         // expensive tiles take about twice as long per wavefront; a launch that is not many times larger than the machine (4 096 - 5 120 wavefronts in
         // flight) ends on those and is faster with one stream per lane.  Measured cross-over (tools/crossover.py, bench.py --steps): bunny 1280x720 at 17 - 20
         // windows (20 windows: 81.0 ms pool, 87.6 ms tiles), TLAS scene at ~28, watch-tower 1920x1080 at 7 — 56 000 ... 100 000 (tile, window) pairs; the
         // threshold sits at the low end of that range.
-        const bool pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * ((nf + 63u) / 64u) >= c->poolMinWaves && (c->poolMinWaves == 0 || nf > 64u);
+        // With the tile costs known (most expensive first + split, see split_point) the pool is never slower than one stream per lane from ~12 windows of 720p on
+        // (tools/split_probe.py: bunny 14 windows 57.8 against 59.6 ms, two-level scene 16 windows 79 against 94 ms, watch-tower 1080p 7 windows 155.6 against 161.1 ms).
+        // The job that MEASURES the tile costs runs the pool whenever it has at least two windows: split_point's two constants are calibrated on pool wavefronts
+        // under load (a render_tiles_kernel job inflates the cheap tiles' durations, not the expensive ones': its sum is no measure of the job's ideal length).
+        const uint64_t minWaves = c->poolMinWaves != 65000u ? c->poolMinWaves : (c->jobCostValid ? 43000u : (wantJobCost ? 1u : 65000u));
+        const bool pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * ((nf + 63u) / 64u) >= minWaves && (c->poolMinWaves == 0 || nf > 64u);
         hipError_t le;
         if (getenv("CRT_DEBUG_FAIL_LAUNCH")) le = hipErrorInvalidConfiguration;       // tests: the runtime refuses the launch
-        else if (pool)
-            le = crt_launch_render_pool(&c->hScene, slab, (char*)slab + (size_t)((nf + 63u) / 64u) * sample_bytes_per_window(c, passes), c->dCounters, c->dTileClocks, c->dTileOrder,
-                                        c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->cfg.collectStats, st);
+        else if (pool) {
+            const uint32_t windows = (nf + 63u) / 64u;
+            const uint32_t H = split_point(c, windows);
+            void* scratch = (char*)slab + (size_t)windows * sample_bytes_per_window(c, passes);
+            hipStream_t st2 = st;
+            le = hipSuccess;
+            if (H) {
+                // the expensive tiles first, one stream per lane, on this launch's stream; the pool for the rest on the next stream, released by the same start event
+                st2 = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
+                le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, 0, nullptr, 0u, nullptr, H, st);
+                if (le == hipSuccess) le = hipStreamWaitEvent(st2, ev.a, 0);
+            }
+            if (le == hipSuccess)
+                le = crt_launch_render_pool(&c->hScene, slab, scratch, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                            spp_first + f0 * passes, nf, passes, c->cfg.collectStats, H, wantJobCost ? c->dJobCost : nullptr, st2);
+            if (H && le == hipSuccess) {
+                if (c->splitEvents.size() < 32) { hipEvent_t e; le = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (le == hipSuccess) c->splitEvents.push_back(e); }
+                if (le == hipSuccess) { hipEvent_t e = c->splitEvents[c->splitSeq++ % c->splitEvents.size()]; le = hipEventRecord(e, st2); if (le == hipSuccess) le = hipStreamWaitEvent(st, e, 0); }
+                if (le == hipSuccess) c->splitLaunches++;
+            }
+        }
         else
             le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, blockDesc, nBlocks, wantCost ? c->dTileCost : nullptr, st);
+                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, blockDesc, nBlocks, wantCost ? c->dTileCost : (wantJobCost ? c->dJobCost : nullptr), 0u, st);
         if (le != hipSuccess) {
             // a launch that failed has rendered nothing: take its timing pair back (a half-recorded pair would poison crt_get_timing), leave the accumulator
             // and the region bookkeeping untouched — the frames before it are in, this one and the rest are not — and report
@@ -1033,6 +1120,11 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         }
         if (pool) c->poolLaunches++;
         HIPCK(c, hipEventRecord(ev.b, st));
+        if (wantJobCost) {
+            HIPCK(c, hipMemcpyAsync(c->hJobCost, c->dJobCost, (size_t)c->tileCount * 4, hipMemcpyDeviceToHost, st));
+            HIPCK(c, hipEventRecord(c->jobCostCopied, st));
+            c->jobCostPending = true;
+        }
         if (wantCost && !pool && !c->latDone) {                                                // the tile costs travel to the host behind the launch; looked at by a later crt_render
             HIPCK(c, hipMemcpyAsync(c->hTileCost, c->dTileCost, (size_t)c->tileCount * 4, hipMemcpyDeviceToHost, st));
             HIPCK(c, hipEventRecord(c->costCopied, st));
@@ -1253,8 +1345,8 @@ int crt_get_timing(crt_ctx* c, crt_timing* out)
     for (auto& ev : c->evRender) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->render_kernel_ms += ms; }
     for (auto& ev : c->evAcc) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->resolve_kernel_ms += ms; }
     out->render_launches = (uint32_t)c->evRender.size() + c->foldedLaunches;
-    out->pool_launches = c->poolLaunches;
-    c->foldedRenderMs = c->foldedAccMs = 0; c->foldedLaunches = 0; c->poolLaunches = 0;
+    out->pool_launches = c->poolLaunches; out->split_launches = c->splitLaunches;
+    c->foldedRenderMs = c->foldedAccMs = 0; c->foldedLaunches = 0; c->poolLaunches = 0; c->splitLaunches = 0;
     for (auto& ev : c->evRender) c->evPool.push_back(ev);      // the figures cover every launch since the previous crt_get_timing
     for (auto& ev : c->evAcc) c->evPool.push_back(ev);
     c->evRender.clear(); c->evAcc.clear();

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                                                            const uint32_t* __restrict__ tileOrder,
                                                            uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                            uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t windows,
-                                                           const uint32_t* __restrict__ blockDesc, uint32_t* __restrict__ tileCost)
+                                                           const uint32_t* __restrict__ blockDesc, uint32_t* __restrict__ tileCost, uint32_t rankCount)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     uint32_t rank, win = 0u, laneBase = 0u, myLanes = 64u;
     if (blockDesc) { const uint32_t d = blockDesc[blockIdx.x]; rank = d & 0xfffffu; laneBase = (d >> 20) & 63u; myLanes = (d >> 26) + 1u; }
     else { rank = blockIdx.x / windows; win = blockIdx.x - rank * windows; }
-    if (rank >= tileCount) return;
+    if (rank >= (blockDesc ? tileCount : rankCount)) return;                        // rankCount <= tileCount: only the first tiles of the order (a split job, abi.cpp)
     const uint32_t tl = blockDesc ? rank : (tileOrder ? tileOrder[rank] : rank);       // (a block table names local tile indices itself)
     sppFirst += win * 64u * passes;
     frames = (frames - win * 64u < 64u) ? frames - win * 64u : 64u;               // frames of THIS window (the last one may be partial)
@@ -838,15 +838,16 @@ extern "C" hipError_t crt_launch_check_reciprocals(unsigned long long* out, hipS
 // blockDesc / nBlocks: latency mode (see the kernel) for a launch of one window, else nullptr / 0; tileCost: nullptr or one uint32 per tile, atomicMax'ed
 extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                         uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
-                                        uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, const uint32_t* blockDesc, uint32_t nBlocks, uint32_t* tileCost, hipStream_t stream)
+                                        uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, const uint32_t* blockDesc, uint32_t nBlocks, uint32_t* tileCost, uint32_t rankCount, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
     const uint32_t windows = (frames + 63u) / 64u;                      // one 64-lane wavefront per (tile, 64-frame window)
     if ((unsigned long long)tileCount * windows > 0x7fffffffull) return hipErrorInvalidValue;
     if (windows != 1u || collectStats || nBlocks == 0u) blockDesc = nullptr;      // latency mode: single-window launches only
     if (blockDesc && tileCount > 0x100000u) return hipErrorInvalidValue;
-    dim3 grid(blockDesc ? nBlocks : tileCount * windows), block(64);
-#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows, blockDesc, tileCost)
+    if (rankCount == 0u || rankCount > tileCount) rankCount = tileCount;          // the first rankCount tiles of the order only (all windows)
+    dim3 grid(blockDesc ? nBlocks : rankCount * windows), block(64);
+#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows, blockDesc, tileCost, rankCount)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH(0, true); else CRT_LAUNCH(0, false); }
     else { if (collectStats) CRT_LAUNCH(1, true); else CRT_LAUNCH(1, false); }
 #undef CRT_LAUNCH

@@ -59,17 +59,25 @@ constexpr uint32_t kQueueMask = 127u;                            // queues are r
 #else
 #define CRT_PSTAMP(var)
 #endif
+#ifdef CRT_POOL_TIMELINE
+// diagnostic build only (-DCRT_POOL_TIMELINE, tools/pool_timeline.py): start / end wall clock (100 MHz) and compute unit of every wavefront of the last launch
+__device__ unsigned long long* g_poolTimeline = nullptr;
+#endif
 template <int KIND, bool COUNT, int S, int SETS>
 __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
                                                              unsigned long long* __restrict__ tileClocks, const uint32_t* __restrict__ tileOrder,
                                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
-                                                             uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t groups)
+                                                             uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t groups, uint32_t rankFirst, uint32_t* __restrict__ tileCost)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    const unsigned long long clk0 = COUNT ? wall_clock64() : 0ull;
-    // block -> (tile rank, group of S frames), rank-major: all groups of the expensive tiles (listed first by the host) are dispatched first
-    const uint32_t rank = blockIdx.x / groups, grp = blockIdx.x - rank * groups;
+#ifdef CRT_POOL_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+#endif
+    const unsigned long long clk0 = (COUNT || tileCost) ? wall_clock64() : 0ull;
+    // block -> (tile rank, group of S frames), rank-major: all groups of the expensive tiles (listed first by the host) are dispatched first;
+    // rankFirst > 0: the tiles before it in the order are rendered by a concurrent render_tiles_kernel launch (a split job, abi.cpp)
+    const uint32_t rank0 = blockIdx.x / groups, grp = blockIdx.x - rank0 * groups, rank = rank0 + rankFirst;
     if (rank >= tileCount) return;
     const uint32_t tl = tileOrder ? tileOrder[rank] : rank;
     const uint32_t frame0 = grp * (uint32_t)S;                                   // first frame (of the launch) of this wave's streams
@@ -508,6 +516,13 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
 #endif
 #undef CRT_TOP
 
+#ifdef CRT_POOL_TIMELINE
+    if (lane == 0 && g_poolTimeline) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_poolTimeline[3 * (size_t)blockIdx.x] = tl0; g_poolTimeline[3 * (size_t)blockIdx.x + 1] = wall_clock64(); g_poolTimeline[3 * (size_t)blockIdx.x + 2] = hw; }
+#endif
+    // what this tile costs (100 MHz ticks), in the unit of a one-stream-per-lane wavefront: this wave's duration scaled to 64 streams, times 5 / 6 (the 128-stream
+    // wavefront of a tile runs 2.4x as long as its render_tiles_kernel wavefront); the host orders and splits later jobs with it
+    // (full groups only: a wavefront with fewer streams than S runs them less densely)
+    if (tileCost && lane == 0 && nStreams == (uint32_t)S) atomicMax(&tileCost[tl], (uint32_t)((wall_clock64() - clk0) * 320ull / (6ull * (uint32_t)S)));
     if (COUNT && tileClocks && lane == 0 && groups == 1u) {                     // instrumentation: per-tile wall time + loop trips (one group per tile only)
         tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
         tileClocks[2 * tl + 1] = trips;
@@ -536,19 +551,34 @@ extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackDepth, uint32_t streams, ui
 // group of streams may reach past the last window, hence 128 stream slots per window)
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t tileCount) { return (size_t)tileCount * 128u * 15u * 4u; }
 
+#ifdef CRT_POOL_TIMELINE
+static unsigned long long* g_timelineHost = nullptr; static size_t g_timelineCount = 0;
+extern "C" size_t crt_debug_pool_timeline(unsigned long long* out, size_t cap)        // after a sync: 3 words per wavefront of the last pool launch
+{
+    const size_t n = g_timelineCount < cap ? g_timelineCount : cap;
+    if (out && n) (void)hipMemcpy(out, g_timelineHost, n * 24, hipMemcpyDeviceToHost);
+    return g_timelineCount;
+}
+#endif
 extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, void* facScratch, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
-                                             uint32_t frames, uint32_t passes, int collectStats, hipStream_t stream)
+                                             uint32_t frames, uint32_t passes, int collectStats, uint32_t rankFirst, uint32_t* tileCost, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
     if (!sc->ref16ok) return hipErrorInvalidValue;                              // the host launches render_tiles_kernel for such scenes
     const uint32_t S = crt_pool_streams(frames);
     const uint32_t groups = (frames + S - 1u) / S;
     if ((unsigned long long)tileCount * groups > 0x7fffffffull) return hipErrorInvalidValue;
-    dim3 grid(tileCount * groups), block(64);
+    if (rankFirst >= tileCount) return hipSuccess;
+    dim3 grid((tileCount - rankFirst) * groups), block(64);
+#ifdef CRT_POOL_TIMELINE
+    { static unsigned long long* buf = nullptr; static size_t cap = 0;
+      if (cap < (size_t)grid.x) { if (buf) (void)hipFree(buf); (void)hipMalloc((void**)&buf, (size_t)grid.x * 24); cap = grid.x; (void)hipMemcpyToSymbol(HIP_SYMBOL(crt::g_poolTimeline), &buf, sizeof(buf)); }
+      (void)hipMemsetAsync(buf, 0, (size_t)grid.x * 24, stream); g_timelineHost = buf; g_timelineCount = grid.x; }
+#endif
     const uint32_t sets = S == 64u ? 1u : (uint32_t)CRT_POOL_SETS;
     const uint32_t ldsBytes = crt_pool_lds_bytes(sc->stackDepth, S, sets);
-#define CRT_LAUNCH(K, C, SS, NS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS, NS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups)
+#define CRT_LAUNCH(K, C, SS, NS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS, NS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups, rankFirst, tileCost)
 #define CRT_LAUNCH_S(K, C) do { if (S == 64u) CRT_LAUNCH(K, C, 64, 1); else CRT_LAUNCH(K, C, CRT_POOL_STREAMS, CRT_POOL_SETS); } while (0)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH_S(0, true); else CRT_LAUNCH_S(0, false); }
     else { if (collectStats) CRT_LAUNCH_S(1, true); else CRT_LAUNCH_S(1, false); }

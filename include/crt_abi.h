@@ -131,6 +131,8 @@ typedef struct crt_timing {                /* covers every launch since the prev
     float resolve_kernel_ms;  /* Σ duration of the ordered accumulate kernels                                        */
     uint32_t render_launches; /* number of path-tracing kernel launches                                              */
     uint32_t pool_launches;   /* ... of which render_pool_kernel (stream pool; the others are render_tiles_kernel)   */
+    uint32_t split_launches;  /* ... of which split: the most expensive tiles by a concurrent render_tiles_kernel    */
+    uint32_t reserved;
 } crt_timing;
 
 /* ---- life cycle ----------------------------------------------------------------------------------- */

@@ -201,7 +201,7 @@ def test_bench_json_contract():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert rf["traffic"] is None            # the PMC figure is attached only to the workload it was collected on
-    assert rf["launches"] == 2 and rf["achieved"] > 0
+    assert rf["launches"] in (1, 2) and rf["achieved"] > 0          # (the warm-up launch enters the average when it ran the same kernel as the timed job)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and "sample" in cb
     assert d["value"] > cb["value"]        # (a 320x192 job is latency-bound on the GPU; the ratio that matters is the full-size bench line's)

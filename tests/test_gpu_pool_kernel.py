@@ -117,3 +117,24 @@ def test_failing_launch_is_reported_and_leaves_the_context_usable(crt, orc, monk
     o, _ = orc.load_scene(scene_path("cube_scene.xml"), 0, ASSETS)
     o.renderer_init(32, 32); o.render(2, 1)
     assert np.array_equal(ctx.accumulator(), o.accumulator())
+
+
+@pytest.mark.parametrize("xml,kind,W,H,frames,passes,force", [("bunny_scene.xml", 0, 160, 96, 320, 1, None), ("bunny_scene.xml", 0, 96, 64, 200, 2, "5"), ("tlas_scene.xml", 1, 96, 64, 256, 1, "23")])
+def test_split_jobs_match_the_oracle(crt, orc, monkeypatch, xml, kind, W, H, frames, passes, force):
+    """Jobs after the first one know what every tile costs: they dispatch the tiles most expensive first and render the most expensive ones with a concurrent
+    render_tiles_kernel launch (abi.cpp split_point).  Same pixels, same counters, whatever the split."""
+    monkeypatch.setenv("CRT_RENDER_KERNEL", "pool_always")
+    if force is None: monkeypatch.setenv("CRT_SPLIT_SLACK", "0.05")          # a small image: make the criterion bite
+    else: monkeypatch.setenv("CRT_SPLIT_FORCE", force)
+    o, _ = orc.load_scene(scene_path(xml), kind, ASSETS)
+    o.renderer_init(W, H); o.set_params(5, passes); o.render(frames, 4)
+    want = o.accumulator()
+    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    ctx = crt.Context(W, H); hs.upload(ctx)
+    splits = []
+    for i in range(3):
+        ctx.clear(); ctx.reset_counters(); ctx.render(1, frames, passes); ctx.sync()
+        assert np.array_equal(ctx.accumulator(), want), i
+        assert ctx.counters()["rays"] == o.counters()["rays"]
+        splits.append(ctx.timing()["split_launches"])
+    assert splits[0] == 0 and splits[-1] == 1, splits          # the first job measures, later ones split
