@@ -103,6 +103,8 @@ struct crt_ctx {
     uint32_t* dJobCost = nullptr; uint32_t* hJobCost = nullptr; hipEvent_t jobCostCopied = nullptr; bool jobCostPending = false, jobCostValid = false;
     std::vector<uint32_t> jobCost;          // per local tile, 100 MHz ticks; sorted view = the tile order on the device once jobCostValid
     std::vector<uint32_t> jobOrder;
+    uint32_t* dJobDesc = nullptr; uint32_t* hJobDesc = nullptr; uint32_t jobDescCap = 0, jobBlocks = 0, jobHead = 0; hipEvent_t jobDescReady = nullptr;
+    uint32_t planWindows = 0, planFrames = 0; bool planPool = false, planValid = false;       // what the table on the device was planned for
     std::vector<hipEvent_t> splitEvents;    // end events of the second kernel of split launches (recycled round-robin)
     size_t splitSeq = 0; uint32_t splitLaunches = 0;
     uint64_t poolMinWaves = 65000; // launches of fewer (tile, 64-frame window) pairs run render_tiles_kernel: see crt_render
@@ -283,6 +285,9 @@ void crt_destroy(crt_ctx* c)
     if (c->dTileOrder) (void)hipFree(c->dTileOrder);
     if (c->dTileCost) (void)hipFree(c->dTileCost);
     if (c->dJobCost) (void)hipFree(c->dJobCost);
+    if (c->dJobDesc) (void)hipFree(c->dJobDesc);
+    if (c->hJobDesc) (void)hipHostFree(c->hJobDesc);
+    if (c->jobDescReady) (void)hipEventDestroy(c->jobDescReady);
     if (c->hJobCost) (void)hipHostFree(c->hJobCost);
     if (c->jobCostCopied) (void)hipEventDestroy(c->jobCostCopied);
     for (auto e : c->splitEvents) (void)hipEventDestroy(e);
@@ -761,7 +766,7 @@ static int update_tile_order(crt_ctx* c)
     for (int k = 0; k <= crt_ctx::kLatStages; k++) { c->tuneCount[k] = 0; c->tuneMs[k] = 0; }
     c->latStage = 0; c->latBest = 0; c->latDone = false; c->latWarm = false; c->costPending = false;
     first.insert(first.end(), rest.begin(), rest.end());
-    c->jobCostValid = false; c->jobCostPending = false;
+    c->jobCostValid = false; c->jobCostPending = false; c->planValid = false;
     { const int r = upload_tile_order(c, first); if (r) return r; }
     c->orderDirty = false;
     return 0;
@@ -780,6 +785,8 @@ static size_t window_bytes(const crt_ctx* c, uint32_t passes) { return sample_by
 // stage starts from the fastest stage so far (its lanes per tile and the costs measured under it), aims at `aim` x that stage's slowest tile, narrows every tile
 // the model says would miss the aim and widens every tile that would make it with wavefronts twice as wide; crt_render times each stage and keeps the fastest.
 // CRT_LAT_POLICY="share:lanes,.." replaces stage 1 by fixed steps (tiles costing >= share x the slowest get `lanes`) and stops there.
+// one entry of a block table: local tile | first frame << 16 | log2(lanes) << 22 | window << 25 (render_tiles_kernel)
+static uint32_t block_desc(uint32_t tile, uint32_t laneBase, uint32_t lanes, uint32_t window) { uint32_t lg = 0; while ((1u << lg) < lanes) lg++; return tile | (laneBase << 16) | (lg << 22) | (window << 25); }
 static const uint32_t kLatLanes[7] = {64u, 32u, 16u, 8u, 4u, 2u, 1u};
 static const double kLatG[7] = {1.0, 0.93, 0.88, 0.79, 0.69, 0.57, 0.48};
 static int lat_index(uint32_t L) { int k = 0; while (k < 6 && kLatLanes[k] != L) k++; return k; }
@@ -793,7 +800,7 @@ static int upload_block_table(crt_ctx* c, const std::vector<uint8_t>& lanes, con
     std::vector<uint32_t> table; table.reserve((size_t)n * 2);
     for (uint32_t r = 0; r < n; r++) {
         const uint32_t tl = order[r], L = lanes[tl];
-        for (uint32_t base = 0; base < 64u; base += L) table.push_back(tl | (base << 20) | ((L - 1u) << 26));
+        for (uint32_t base = 0; base < 64u; base += L) table.push_back(block_desc(tl, base, L, 0u));
     }
     if (table.size() > 0x7fffffffull) return c->fail(CRT_ERR_INVALID, "block table too large");
     if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] latency table: %zu wavefronts for %u tiles (slowest tile of the base stage %.2f ms)\n", table.size(), n, n ? cost[order[0]] * 1e-5 : 0.0);
@@ -986,27 +993,92 @@ static int adopt_job_costs(crt_ctx* c)
     c->jobOrder.resize(n);
     for (uint32_t i = 0; i < n; i++) c->jobOrder[i] = i;
     std::stable_sort(c->jobOrder.begin(), c->jobOrder.end(), [&](uint32_t a, uint32_t b) { return c->jobCost[a] > c->jobCost[b]; });
-    c->jobCostValid = true;
+    c->jobCostValid = true; c->planValid = false;
     return upload_tile_order(c, c->jobOrder);
 }
 
-// Split point of a pool job of `windows` windows: the stream pool executes a third fewer instructions per sample, but its wavefronts own 128 streams for 64 lanes —
-// the wavefronts of the most expensive tiles run 2.4x as long as a one-stream-per-lane wavefront of the same tile (bunny: 82 ms against 34 ms), and a job that is
-// not many times longer than that ends on them with the chip nearly empty (tools/pool_timeline.py: 20 windows, 4 096 waves in flight until 65 ms, then a tail to
-// 83 ms).  With the tile costs known, the first H tiles of the (cost-sorted) order — those whose pool wavefront would outlast 0.9 x the job's ideal length
-// (total wave time / wavefronts in flight) — are rendered by a concurrent render_tiles_kernel launch instead (all windows, dispatched first), the rest by the pool.
-static uint32_t split_point(const crt_ctx* c, uint32_t windows)
+// Plan of a job (one launch of `windows` windows) once the tile costs are known.  A launch ends on its slowest wavefront, and how long a wavefront runs is set by
+// the serial chains of its streams: per tile and window, a stream-pool wavefront (128 streams on 64 lanes; the fewest instructions per sample) runs 2.4x as long
+// as a one-stream-per-lane wavefront of render_tiles_kernel, and that one can be cut further by handing the tile's 64 streams to 64 / L wavefronts of L lanes
+// (kLatG; at 64 / L times the instruction issue).  A job many times longer than its slowest pool wavefront should be all pool; a short one (few windows, or one
+// rank's share of a multi-GPU tile split) ends on those wavefronts with the chip nearly empty (tools/pool_timeline.py: 20 windows of the bunny, 4 096 waves in
+// flight until 65 ms, then a tail to 83 ms).  The plan is the smallest makespan T for which every tile can take the CHEAPEST class whose wavefronts last <= T
+//     pool (2.4 c, if this launch may use the pool) | one wavefront per window (1.1 c under load) | 64 / L wavefronts per window (g(L) c)
+// and the machine time of all of them (wave time / wavefronts the chip advances at once) still fits T.  Tiles are sorted by cost, so the classes are contiguous:
+// the first `head` tiles of the order go to a block table (render_tiles_kernel, dispatched first), the rest to the pool launch — or, in a launch without the pool,
+// everything goes to the table as soon as one tile needs narrow wavefronts.  Returns the table's blocks in `table` (empty: no table needed).
+static void plan_job(const crt_ctx* c, uint32_t windows, uint32_t frames, bool pool, std::vector<uint32_t>& table, uint32_t* head)
 {
-    if (!c->jobCostValid || windows < 2u || c->cfg.collectStats || c->streams.size() < 2 || getenv("CRT_SPLIT_OFF")) return 0u;
-    if (const char* e = getenv("CRT_SPLIT_FORCE")) { const uint32_t h = (uint32_t)atoi(e); return h < c->tileCount ? h : c->tileCount - 1u; }      // tests
-    double poolLong = 2.4, slack = 1.0;
-    if (const char* e = getenv("CRT_SPLIT_SLACK")) slack = atof(e);
-    double sum = 0; for (uint32_t v : c->jobCost) sum += (double)v;
-    const double ideal = 0.5 * poolLong * (double)windows * sum / 4096.0;       // every tile in the pool: windows / 2 wavefronts of 2.4 x cost each, 4 096 in flight
-    uint32_t H = 0;
-    while (H < c->tileCount / 4u && poolLong * (double)c->jobCost[c->jobOrder[H]] > slack * ideal) H++;
-    if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] job of %u windows: ideal %.1f ms, most expensive tile %.2f ms (pool wavefront %.1f ms), %u tiles to render_tiles_kernel\n", windows, ideal * 1e-5, c->jobCost[c->jobOrder[0]] * 1e-5, poolLong * c->jobCost[c->jobOrder[0]] * 1e-5, H);
-    return H;
+    table.clear(); *head = 0;
+    const uint32_t n = c->tileCount;
+    if (!c->jobCostValid || windows < 2u || windows > 64u || n > 0x10000u || c->cfg.collectStats || getenv("CRT_SPLIT_OFF")) return;
+    if (pool && c->streams.size() < 2) return;
+    if (const char* e = getenv("CRT_SPLIT_FORCE")) {                      // tests: the first h tiles through the table, alternating wavefront widths
+        const uint32_t h = std::min<uint32_t>((uint32_t)atoi(e), pool ? n - 1u : n);
+        static const uint32_t Ls[4] = {64u, 16u, 2u, 1u};
+        for (uint32_t r = 0; r < (pool ? h : n); r++) { const uint32_t L = r < h ? Ls[r & 3u] : 64u; for (uint32_t w = 0; w < windows; w++) for (uint32_t b0 = 0; b0 < 64u; b0 += L) table.push_back(block_desc(c->jobOrder[r], b0, L, w)); }
+        *head = h; return;
+    }
+    // cost unit: a pool wavefront's duration per 64 streams while the costs were measured (render_pool_kernel).  In a saturated job the wavefronts of the most expensive
+    // tiles run 1.2x longer than that (82 ms against 68 ms on the bunny); one-stream-per-lane wavefronts need 1.2x the machine time of the pool's.
+    double poolLong = 2.4, wideLoad = 1.1, poolSlots = 4096.0, wideMt = 1.2, narrowSlots = 3500.0;
+    if (const char* e = getenv("CRT_PLAN_NARROW_SLOTS")) narrowSlots = atof(e);
+    const double K = (double)windows;
+    // machine time (ticks) of tile cost v in the cheapest class that lasts <= T; cls: 0 pool, 1 wide, 2 + k narrow (kLatLanes[k])
+    auto cheapest = [&](double v, double T, int* cls) -> double {
+        if (pool && poolLong * v <= T) { *cls = 0; return K * v / poolSlots; }
+        if (wideLoad * v <= T) { *cls = 1; return K * wideMt * v / poolSlots; }
+        int k = 1; while (k < 6 && kLatG[k] * v > T) k++;
+        *cls = 2 + k; return K * (64.0 / kLatLanes[k]) * kLatG[k] * v / narrowSlots;
+    };
+    auto machine = [&](double T) { double m = 0; int cls; for (uint32_t v : c->jobCost) m += cheapest((double)v, T, &cls); return m; };
+    const double top = (double)c->jobCost[c->jobOrder[0]];
+    double lo = top * kLatG[6], hi = std::max(poolLong * top, machine(1e30)) * 1.01;
+    if (machine(lo) <= lo) hi = lo;
+    else for (int it = 0; it < 50; it++) { const double mid = 0.5 * (lo + hi); if (machine(mid) <= mid) hi = mid; else lo = mid; }
+    const double T = hi;
+    uint32_t h = 0, narrow = 0; std::vector<uint8_t> lanes(n, 64);
+    for (uint32_t r = 0; r < n; r++) {
+        int cls; (void)cheapest((double)c->jobCost[c->jobOrder[r]], T, &cls);
+        if (cls != 0) h = r + 1u;
+        if (cls >= 2) { lanes[r] = (uint8_t)kLatLanes[cls - 2]; narrow++; }
+    }
+    if (pool && h >= n) h = n - 1u;
+    if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] job of %u windows, %u tiles: makespan aim %.1f ms (most expensive tile %.2f ms); %u tiles to the block table, %u of them narrow, %s\n", windows, n, T * 1e-5, top * 1e-5, pool ? h : (narrow ? n : 0u), narrow, pool ? "rest to the pool" : "no pool");
+    if (pool ? h == 0u : narrow == 0u) return;
+    const uint32_t upto = pool ? h : n;
+    for (uint32_t r = 0; r < upto; r++) {
+        const uint32_t L = lanes[r];
+        for (uint32_t w = 0; w < windows; w++) {
+            const uint32_t fw = std::min(64u, frames - w * 64u);               // frames of this window: no wavefronts for frames past the end
+            for (uint32_t b0 = 0; b0 < fw; b0 += L) table.push_back(block_desc(c->jobOrder[r], b0, L, w));
+        }
+    }
+    *head = pool ? h : 0u;
+}
+
+// ... and its table on the device (cached for launches of the same shape)
+static int install_job_plan(crt_ctx* c, uint32_t windows, uint32_t frames, bool pool)
+{
+    if (c->planValid && c->planWindows == windows && c->planFrames == frames && c->planPool == pool) return 0;
+    std::vector<uint32_t> table; uint32_t head = 0;
+    plan_job(c, windows, frames, pool, table, &head);
+    c->planValid = true; c->planWindows = windows; c->planFrames = frames; c->planPool = pool; c->jobHead = head; c->jobBlocks = (uint32_t)table.size();
+    if (table.empty()) return 0;
+    if (c->jobDescCap < table.size()) {
+        if (c->dJobDesc) (void)hipFree(c->dJobDesc);
+        if (c->hJobDesc) (void)hipHostFree(c->hJobDesc);
+        c->dJobDesc = nullptr; c->hJobDesc = nullptr; c->jobDescCap = 0;
+        const size_t cap = table.size() + table.size() / 2;
+        HIPCK(c, hipMalloc((void**)&c->dJobDesc, cap * 4));
+        HIPCK(c, hipHostMalloc((void**)&c->hJobDesc, cap * 4, hipHostMallocDefault));
+        c->jobDescCap = (uint32_t)cap;
+    } else if (c->jobDescReady) HIPCK(c, hipEventSynchronize(c->jobDescReady));
+    if (!c->jobDescReady) HIPCK(c, hipEventCreateWithFlags(&c->jobDescReady, hipEventDisableTiming));
+    memcpy(c->hJobDesc, table.data(), table.size() * 4);
+    HIPCK(c, hipMemcpyAsync(c->dJobDesc, c->hJobDesc, table.size() * 4, hipMemcpyHostToDevice, c->stream));      // main stream: behind every launch submitted so far
+    HIPCK(c, hipEventRecord(c->jobDescReady, c->stream));
+    return 0;
 }
 
 int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
@@ -1042,7 +1114,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         if ((r = take_event(c, c->evRender, &ev))) return r;
         // latency mode of a single-window launch (render_tiles_kernel): one wavefront per tile, or the current block table (see next_block_table)
         const uint32_t* blockDesc = nullptr; uint32_t nBlocks = 0; bool wantCost = false;
-        if (nf <= 64u && nf >= 8u && !c->cfg.collectStats && !getenv("CRT_LAT_OFF")) {
+        if (nf <= 64u && nf >= 8u && !c->cfg.collectStats && c->tileCount <= 0x10000u && !getenv("CRT_LAT_OFF")) {
             if (c->costPending && hipEventQuery(c->costCopied) == hipSuccess) { c->costPending = false; harvest_tuning(c); if ((r = next_block_table(c))) return r; }
             const int stage = c->latStage;
             if (stage) { blockDesc = c->dBlockDesc; nBlocks = c->nBlocks; HIPCK(c, hipStreamWaitEvent(st, c->descReady, 0)); }
@@ -1087,31 +1159,37 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         const bool pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * ((nf + 63u) / 64u) >= minWaves && (c->poolMinWaves == 0 || nf > 64u);
         hipError_t le;
         if (getenv("CRT_DEBUG_FAIL_LAUNCH")) le = hipErrorInvalidConfiguration;       // tests: the runtime refuses the launch
-        else if (pool) {
+        else {
             const uint32_t windows = (nf + 63u) / 64u;
-            const uint32_t H = split_point(c, windows);
-            void* scratch = (char*)slab + (size_t)windows * sample_bytes_per_window(c, passes);
-            hipStream_t st2 = st;
+            uint32_t head = 0, jobBlocks = 0;
+            if (nf > 64u && c->jobCostValid) { if ((r = install_job_plan(c, windows, nf, pool))) return r; head = c->jobHead; jobBlocks = c->jobBlocks; }
+            if (jobBlocks) HIPCK(c, hipStreamWaitEvent(st, c->jobDescReady, 0));
             le = hipSuccess;
-            if (H) {
-                // the expensive tiles first, one stream per lane, on this launch's stream; the pool for the rest on the next stream, released by the same start event
-                st2 = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
+            if (pool) {
+                void* scratch = (char*)slab + (size_t)windows * sample_bytes_per_window(c, passes);
+                hipStream_t st2 = st;
+                if (jobBlocks) {
+                    // the expensive tiles first, through the block table, on this launch's stream; the pool for the rest on the next stream, released by the same start event
+                    st2 = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
+                    le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                           spp_first + f0 * passes, nf, passes, c->ldsBytes, 0, c->dJobDesc, jobBlocks, nullptr, 0u, st);
+                    if (le == hipSuccess) le = hipStreamWaitEvent(st2, ev.a, 0);
+                }
+                if (le == hipSuccess)
+                    le = crt_launch_render_pool(&c->hScene, slab, scratch, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                                spp_first + f0 * passes, nf, passes, c->cfg.collectStats, jobBlocks ? head : 0u, wantJobCost ? c->dJobCost : nullptr, st2);
+                if (jobBlocks && le == hipSuccess) {
+                    if (c->splitEvents.size() < 32) { hipEvent_t e; le = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (le == hipSuccess) c->splitEvents.push_back(e); }
+                    if (le == hipSuccess) { hipEvent_t e = c->splitEvents[c->splitSeq++ % c->splitEvents.size()]; le = hipEventRecord(e, st2); if (le == hipSuccess) le = hipStreamWaitEvent(st, e, 0); }
+                }
+            } else {
+                const bool job = jobBlocks != 0u;
                 le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, 0, nullptr, 0u, nullptr, H, st);
-                if (le == hipSuccess) le = hipStreamWaitEvent(st2, ev.a, 0);
+                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, job ? c->dJobDesc : blockDesc, job ? jobBlocks : nBlocks,
+                                       wantCost ? c->dTileCost : (wantJobCost ? c->dJobCost : nullptr), 0u, st);
             }
-            if (le == hipSuccess)
-                le = crt_launch_render_pool(&c->hScene, slab, scratch, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                            spp_first + f0 * passes, nf, passes, c->cfg.collectStats, H, wantJobCost ? c->dJobCost : nullptr, st2);
-            if (H && le == hipSuccess) {
-                if (c->splitEvents.size() < 32) { hipEvent_t e; le = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (le == hipSuccess) c->splitEvents.push_back(e); }
-                if (le == hipSuccess) { hipEvent_t e = c->splitEvents[c->splitSeq++ % c->splitEvents.size()]; le = hipEventRecord(e, st2); if (le == hipSuccess) le = hipStreamWaitEvent(st, e, 0); }
-                if (le == hipSuccess) c->splitLaunches++;
-            }
+            if (jobBlocks && le == hipSuccess) c->splitLaunches++;
         }
-        else
-            le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                   spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, blockDesc, nBlocks, wantCost ? c->dTileCost : (wantJobCost ? c->dJobCost : nullptr), 0u, st);
         if (le != hipSuccess) {
             // a launch that failed has rendered nothing: take its timing pair back (a half-recorded pair would poison crt_get_timing), leave the accumulator
             // and the region bookkeeping untouched — the frames before it are in, this one and the rest are not — and report

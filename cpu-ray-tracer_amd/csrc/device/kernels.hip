@@ -85,9 +85,10 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     // trip of that wave pays for all the phases its 64 lanes populate (NODE and TRI nearly always; a lone wave issues one instruction per 6 - 9 cycles
     // whatever its lane count, tools/microbench/lone_wave.hip).  The host therefore measures the tiles (tileCost, below) and gives the expensive ones
     // to SEVERAL wavefronts of fewer lanes each: fewer phases are populated per trip, so each stream's serial chain advances faster, and the idle part of the
-    // chip takes the extra wavefronts.  blockDesc[block] = local tile index | first frame << 20 | (lanes - 1) << 26; blocks are listed most expensive tile first.
+    // chip takes the extra wavefronts.  blockDesc[block] = local tile index | first frame << 16 | log2(lanes) << 22 | window << 25; blocks are listed most expensive tile first.  (A job of
+    // several windows uses the same table form for its most expensive tiles, abi.cpp build_job_table.)
     uint32_t rank, win = 0u, laneBase = 0u, myLanes = 64u;
-    if (blockDesc) { const uint32_t d = blockDesc[blockIdx.x]; rank = d & 0xfffffu; laneBase = (d >> 20) & 63u; myLanes = (d >> 26) + 1u; }
+    if (blockDesc) { const uint32_t d = blockDesc[blockIdx.x]; rank = d & 0xffffu; laneBase = (d >> 16) & 63u; myLanes = 1u << ((d >> 22) & 7u); win = d >> 25; }
     else { rank = blockIdx.x / windows; win = blockIdx.x - rank * windows; }
     if (rank >= (blockDesc ? tileCount : rankCount)) return;                        // rankCount <= tileCount: only the first tiles of the order (a split job, abi.cpp)
     const uint32_t tl = blockDesc ? rank : (tileOrder ? tileOrder[rank] : rank);       // (a block table names local tile indices itself)
@@ -835,7 +836,7 @@ extern "C" hipError_t crt_launch_check_reciprocals(unsigned long long* out, hipS
     return hipGetLastError();
 }
 
-// blockDesc / nBlocks: latency mode (see the kernel) for a launch of one window, else nullptr / 0; tileCost: nullptr or one uint32 per tile, atomicMax'ed
+// blockDesc / nBlocks: block table (see the kernel; the launch renders exactly the table's blocks), else nullptr / 0; tileCost: nullptr or one uint32 per tile, atomicMax'ed
 extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                         uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
                                         uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, const uint32_t* blockDesc, uint32_t nBlocks, uint32_t* tileCost, uint32_t rankCount, hipStream_t stream)
@@ -843,8 +844,8 @@ extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::C
     if (tileCount == 0 || frames == 0) return hipSuccess;
     const uint32_t windows = (frames + 63u) / 64u;                      // one 64-lane wavefront per (tile, 64-frame window)
     if ((unsigned long long)tileCount * windows > 0x7fffffffull) return hipErrorInvalidValue;
-    if (windows != 1u || collectStats || nBlocks == 0u) blockDesc = nullptr;      // latency mode: single-window launches only
-    if (blockDesc && tileCount > 0x100000u) return hipErrorInvalidValue;
+    if (collectStats || nBlocks == 0u) blockDesc = nullptr;
+    if (blockDesc && (tileCount > 0x10000u || windows > 64u)) return hipErrorInvalidValue;
     if (rankCount == 0u || rankCount > tileCount) rankCount = tileCount;          // the first rankCount tiles of the order only (all windows)
     dim3 grid(blockDesc ? nBlocks : rankCount * windows), block(64);
 #define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows, blockDesc, tileCost, rankCount)

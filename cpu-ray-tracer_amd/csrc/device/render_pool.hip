@@ -519,10 +519,9 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
 #ifdef CRT_POOL_TIMELINE
     if (lane == 0 && g_poolTimeline) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_poolTimeline[3 * (size_t)blockIdx.x] = tl0; g_poolTimeline[3 * (size_t)blockIdx.x + 1] = wall_clock64(); g_poolTimeline[3 * (size_t)blockIdx.x + 2] = hw; }
 #endif
-    // what this tile costs (100 MHz ticks), in the unit of a one-stream-per-lane wavefront: this wave's duration scaled to 64 streams, times 5 / 6 (the 128-stream
-    // wavefront of a tile runs 2.4x as long as its render_tiles_kernel wavefront); the host orders and splits later jobs with it
-    // (full groups only: a wavefront with fewer streams than S runs them less densely)
-    if (tileCost && lane == 0 && nStreams == (uint32_t)S) atomicMax(&tileCost[tl], (uint32_t)((wall_clock64() - clk0) * 320ull / (6ull * (uint32_t)S)));
+    // what this tile costs (100 MHz ticks): this wavefront's duration per 64 streams (close to what the tile's one-stream-per-lane wavefront takes on an idle chip);
+    // full groups only — a wavefront with fewer streams than S runs them less densely.  The host orders and plans later jobs with it (abi.cpp plan_job).
+    if (tileCost && lane == 0 && nStreams == (uint32_t)S) atomicMax(&tileCost[tl], (uint32_t)((wall_clock64() - clk0) * 64ull / (uint32_t)S));
     if (COUNT && tileClocks && lane == 0 && groups == 1u) {                     // instrumentation: per-tile wall time + loop trips (one group per tile only)
         tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
         tileClocks[2 * tl + 1] = trips;

@@ -119,13 +119,13 @@ def test_failing_launch_is_reported_and_leaves_the_context_usable(crt, orc, monk
     assert np.array_equal(ctx.accumulator(), o.accumulator())
 
 
-@pytest.mark.parametrize("xml,kind,W,H,frames,passes,force", [("bunny_scene.xml", 0, 160, 96, 320, 1, None), ("bunny_scene.xml", 0, 96, 64, 200, 2, "5"), ("tlas_scene.xml", 1, 96, 64, 256, 1, "23")])
+@pytest.mark.parametrize("xml,kind,W,H,frames,passes,force", [("bunny_scene.xml", 0, 160, 96, 320, 1, None), ("bunny_scene.xml", 0, 96, 64, 200, 2, "5"), ("tlas_scene.xml", 1, 96, 64, 256, 1, "23"), ("bunny_scene.xml", 0, 96, 64, 130, 1, "tiles")])
 def test_split_jobs_match_the_oracle(crt, orc, monkeypatch, xml, kind, W, H, frames, passes, force):
     """Jobs after the first one know what every tile costs: they dispatch the tiles most expensive first and render the most expensive ones with a concurrent
-    render_tiles_kernel launch (abi.cpp split_point).  Same pixels, same counters, whatever the split."""
-    monkeypatch.setenv("CRT_RENDER_KERNEL", "pool_always")
-    if force is None: monkeypatch.setenv("CRT_SPLIT_SLACK", "0.05")          # a small image: make the criterion bite
-    else: monkeypatch.setenv("CRT_SPLIT_FORCE", force)
+    render_tiles_kernel launch driven by a block table (abi.cpp plan_job).  Same pixels, same counters, whatever the split."""
+    monkeypatch.setenv("CRT_RENDER_KERNEL", "tiles" if force == "tiles" else "pool_always")
+    if force == "tiles": monkeypatch.setenv("CRT_SPLIT_FORCE", "7")          # a job below the pool's size: everything through the table, 7 tiles with narrow wavefronts
+    elif force is not None: monkeypatch.setenv("CRT_SPLIT_FORCE", force)     # (None: whatever the planner decides for this small image)
     o, _ = orc.load_scene(scene_path(xml), kind, ASSETS)
     o.renderer_init(W, H); o.set_params(5, passes); o.render(frames, 4)
     want = o.accumulator()
@@ -137,4 +137,4 @@ def test_split_jobs_match_the_oracle(crt, orc, monkeypatch, xml, kind, W, H, fra
         assert np.array_equal(ctx.accumulator(), want), i
         assert ctx.counters()["rays"] == o.counters()["rays"]
         splits.append(ctx.timing()["split_launches"])
-    assert splits[0] == 0 and splits[-1] == 1, splits          # the first job measures, later ones split
+    assert splits[0] == 0 and (force is None or splits[-1] == 1), splits          # the first job measures, later ones split

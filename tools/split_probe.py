@@ -12,7 +12,8 @@ crt = importlib.util.module_from_spec(spec); spec.loader.exec_module(crt)
 A = os.path.join(REPO, "assets")
 K, xml, kind, W, H = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 sc = crt.HostScene(os.path.join(A, "scenes", xml), kind, A)
-ctx = crt.Context(W, H); sc.upload(ctx); ctx.reserve(64 * K, 1)
+stride = int(os.environ.get("PROBE_TILE_STRIDE", "1")); tiles = (W // 16) * (H // 16)          # (stride N: the tiles one rank of an N-GPU tile split owns)
+ctx = crt.Context(W, H, tile_stride=stride, tile_count=(tiles + stride - 1) // stride if stride > 1 else -1); sc.upload(ctx); ctx.reserve(64 * K, 1)
 ts = []
 for i in range(4):
     ctx.clear(); ctx.sync(); t0 = time.perf_counter(); ctx.render(1, 64 * K, 1); ctx.sync(); ts.append((time.perf_counter() - t0) * 1e3); tm = ctx.timing()
@@ -22,8 +23,10 @@ Ks = [int(k) for k in (sys.argv[1] if len(sys.argv) > 1 else "20").split(",")]
 scene = sys.argv[2:6] if len(sys.argv) > 5 else ["bunny_scene.xml", "0", "1280", "720"]
 for K in Ks:
     variants = [("default", {}), ("no split", {"CRT_SPLIT_OFF": "1"}), ("tiles kernel", {"CRT_RENDER_KERNEL": "tiles"})]
-    for sl in os.environ.get("PROBE_SLACKS", "").split(","):
-        if sl: variants.append(("pool always, slack " + sl, {"CRT_RENDER_KERNEL": "pool_always", "CRT_SPLIT_SLACK": sl}))
+    for sl in os.environ.get("PROBE_NARROW_SLOTS", "").split(","):
+        if sl: variants.append(("narrow slots " + sl, {"CRT_PLAN_NARROW_SLOTS": sl}))
     for name, env in variants:
         r = subprocess.run([sys.executable, "-c", child, str(K)] + scene, env=dict(os.environ, **env), capture_output=True, text=True)
         print("K = %2d  %-26s %s %s" % (K, name, r.stdout.strip(), r.stderr.strip()[-300:] if r.returncode else ""), flush=True)
+        crt_lines = [l for l in r.stderr.splitlines() if l.startswith("[crt] job")]
+        if crt_lines: print("        " + crt_lines[-1])
