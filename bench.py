@@ -122,7 +122,7 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("CRT_BENCH_FORCE_DIST"):      # (FORCE_DIST: a one-rank RCCL rehearsal on a one-GPU box — init, reduce / all_reduce, barrier all run)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("CRT_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse the N > 1 code path on a one-GPU box
@@ -266,7 +266,7 @@ def main():
                                   "" if world == 1 else ("; every one of the %d ranks renders its own %d windows, ONE RCCL all-reduce of the float4 accumulator closes the job" % (world, args.steps)
                                                          if args.split == "frames" else "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE RCCL %s of the float4 accumulator closes the job" % (world, collective["used"]))),
                    "latency_ms_single_step": round(single_ms, 3) if single_ms else None,
-                   "collective": None if world == 1 else collective["used"], "rccl_ranks": None if dist is None else dist.get_world_size(), "backend": None if dist is None else dist.get_backend(),
+                   "collective": None if dist is None else collective["used"], "rccl_ranks": None if dist is None else dist.get_world_size(), "backend": None if dist is None else dist.get_backend(),
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
                    "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},
         "single_render": None if not single_ms else {"ms": round(single_ms, 3), "mrays_s": round(counts["rays"] / single_ms / 1e3, 1), "first_ms": round(lat[0], 3), "untuned_ms": round(lat[1], 3),

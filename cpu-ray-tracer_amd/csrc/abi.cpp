@@ -830,7 +830,7 @@ static int next_block_table(crt_ctx* c)
     if (s == 0 && !c->latWarm) { c->latWarm = true; return 0; }          // measure the one-wave launch once more, warm
     c->latCost[s].assign(c->hTileCost, c->hTileCost + n);
     if (s == 0) c->latL[0].assign(n, 64);
-    if (c->tuneCount[s] && (c->latBest == s || c->tuneMs[s] < c->tuneMs[c->latBest])) c->latBest = s;
+    if (c->tuneCount[s] && (c->latBest == s || !c->tuneCount[c->latBest] || c->tuneMs[s] < c->tuneMs[c->latBest])) c->latBest = s;
     bool last = s >= K;
     std::vector<std::pair<double, uint32_t>> steps;
     if (const char* e = getenv("CRT_LAT_POLICY")) {
@@ -1418,6 +1418,7 @@ int crt_get_timing(crt_ctx* c, crt_timing* out)
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipStreamSynchronize(c->stream));
     for (auto st : c->streams) HIPCK(c, hipStreamSynchronize(st));
+    harvest_tuning(c);                                         // the latency mode's stage timings, before the pairs are recycled
     memset(out, 0, sizeof(*out));
     out->render_kernel_ms = (float)c->foldedRenderMs; out->resolve_kernel_ms = (float)c->foldedAccMs;
     for (auto& ev : c->evRender) { float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, ev.a, ev.b)); out->render_kernel_ms += ms; }
