@@ -275,7 +275,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "hbm_actual_frac": None if not traffic or job_launch_ms <= 0 else round(traffic / (job_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "limiter": "valu_issue (fp32 instruction issue on divergent code; the algorithmic bytes are served by L2: see hbm_actual_frac and valu_issue)",
-                     "kernel": job_kernel, "avg_launch_ms": round(avg_launch_ms, 4), "launches": all_launches,
+                     "kernel": job_kernel, "job_split": bool(tm.get("split_launches", 0)), "avg_launch_ms": round(avg_launch_ms, 4), "launches": all_launches,
                      "algorithmic_bytes_per_launch": int(alg_bytes_launch),
                      "job_launch_ms": round(job_launch_ms, 4), "job_launch_windows": round(1 / launches_per_step, 2) if launches_per_step else None,
                      "job_launch_achieved": round(algorithmic_bytes(counts) / max(launches_per_step, 1e-9) / (job_launch_ms * 1e-3) / 1e9, 2) if job_launch_ms > 0 else None,
@@ -287,7 +287,7 @@ def main():
                          "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
                          "note": "the limiter in practice: SQ_INSTS_VALU of the job's launch (PMC pass, per window x windows of this launch) / its duration, against the chip's measured fp32 VALU issue peak; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)"},
                      "counters_per_step": {k: round(v) for k, v in counts.items()},
-                     "note": "achieved = mean algorithmic bytes per render_tiles_kernel launch / mean launch duration over all its launches in this process (warm-up job + timed job; HIP events on the launch stream) = the average rocprofv3 --stats reports; job_launch_* = the timed job's launch alone; job_achieved = algorithmic GB/s over the whole timed region incl. the ordered accumulate; the bytes are algorithmic (SURVEY 8(d)) and mostly served by L2 — traffic = HBM bytes of the job's launch from the PMC passes (per window x windows), hbm_actual_frac = traffic / job launch time / peak"},
+                     "note": "achieved = mean algorithmic bytes per " + job_kernel + " launch / mean launch duration over all its launches in this process (warm-up job + timed job; HIP events on the launch stream) = the average rocprofv3 --stats reports; job_launch_* = the timed job's launch alone (job_split: its most expensive tiles ran beside it in a concurrent render_tiles_kernel launch driven by a block table, inside the same event pair); job_achieved = algorithmic GB/s over the whole timed region incl. the ordered accumulate; the bytes are algorithmic (SURVEY 8(d)) and mostly served by L2 — traffic = HBM bytes of the job's launch from the PMC passes (per window x windows), hbm_actual_frac = traffic / job launch time / peak"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(xml, args.kind, W, H)
