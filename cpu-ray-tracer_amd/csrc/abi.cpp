@@ -17,9 +17,10 @@
 #include <algorithm>
 #include <vector>
 
-extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, const uint32_t*, uint32_t, uint32_t*, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, const uint32_t*, uint32_t, uint32_t*, uint32_t, unsigned long long*, hipStream_t);
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
-extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t*, hipStream_t);
+extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t*, unsigned long long*, hipStream_t);
+extern "C" uint32_t crt_pool_streams(uint32_t frames);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_whitted(const crt::Scene*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
@@ -101,6 +102,8 @@ struct crt_ctx {
     // Jobs (launches of several windows): what each tile costs is measured once per camera / scene by the first job launch (every wavefront's duration, scaled to
     // 64 streams); later launches dispatch the tiles most expensive first and SPLIT: see split_point
     uint32_t* dJobCost = nullptr; uint32_t* hJobCost = nullptr; hipEvent_t jobCostCopied = nullptr; bool jobCostPending = false, jobCostValid = false;
+    uint32_t recWaves = 0, recResident = 0, recWindows = 0; bool recPool = false;     // the measuring launch: wavefronts, how many the chip holds, windows, kernel
+    double poolWindowTicks = 0;             // machine time of ONE window of this image under the pool, 100 MHz ticks (0: unknown)
     std::vector<uint32_t> jobCost;          // per local tile, 100 MHz ticks; sorted view = the tile order on the device once jobCostValid
     std::vector<uint32_t> jobOrder;
     uint32_t* dJobDesc = nullptr; uint32_t* hJobDesc = nullptr; uint32_t jobDescCap = 0, jobBlocks = 0, jobHead = 0; hipEvent_t jobDescReady = nullptr;
@@ -985,11 +988,27 @@ static int take_region(crt_ctx* c, size_t need, hipStream_t st, size_t* offOut)
     }
 }
 
-// A job's tile costs have arrived (hJobCost): dispatch order = most expensive tile first from now on
+// the job-cost buffer: one uint32 per tile, then (8-byte aligned) three uint64: ~(first wavefront's start clock), last wavefront's start clock, wave time after it
+static size_t job_cost_clk_offset(const crt_ctx* c) { return (((size_t)c->tileCount + 1u) & ~(size_t)1u) * 4u; }
+static size_t job_cost_bytes(const crt_ctx* c) { return job_cost_clk_offset(c) + 24u; }
+
+// A job's tile costs have arrived (hJobCost): dispatch order = most expensive tile first from now on; and what ONE window of this image costs the machine under
+// the pool — the planner's yardstick.  The sum of the wavefront durations is no measure of it (waves that share a SIMD with four others last longer; the
+// expensive tiles' wavefronts, which outlive the crowd, do not), so it comes from the launch's dispatch: a launch that oversubscribes the chip keeps every wavefront
+// slot busy until its last wavefront starts (S0 = last start - first start), and drains afterwards — the wave time spent after S0, summed by the wavefronts
+// themselves, divided by the slots.  One-stream-per-lane launches need 1.2x the pool's machine time (4.24 against 3.52 ms per window on the bunny).
 static int adopt_job_costs(crt_ctx* c)
 {
     const uint32_t n = c->tileCount;
     c->jobCost.assign(c->hJobCost, c->hJobCost + n);
+    {
+        const unsigned long long* clk = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(c->hJobCost) + job_cost_clk_offset(c));
+        const double s0 = (clk[0] && clk[1] && clk[1] > ~clk[0]) ? (double)(clk[1] - ~clk[0]) : 0.0;
+        const double drain = (double)clk[2] / (double)(c->recResident ? c->recResident : 1u);
+        c->poolWindowTicks = 0;
+        if (c->recWindows && (double)c->recWaves >= 1.5 * (double)c->recResident && s0 > 0) c->poolWindowTicks = (s0 + drain) / (double)c->recWindows / (c->recPool ? 1.0 : 1.2);
+        if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] measured %u windows with %s: %u wavefronts, last one started %.2f ms after the first, then %.2f ms of drain -> %.3f ms of machine time per window under the pool\n", c->recWindows, c->recPool ? "the pool" : "one stream per lane", c->recWaves, s0 * 1e-5, drain * 1e-5, c->poolWindowTicks * 1e-5);
+    }
     c->jobOrder.resize(n);
     for (uint32_t i = 0; i < n; i++) c->jobOrder[i] = i;
     std::stable_sort(c->jobOrder.begin(), c->jobOrder.end(), [&](uint32_t a, uint32_t b) { return c->jobCost[a] > c->jobCost[b]; });
@@ -1024,10 +1043,14 @@ static void plan_job(const crt_ctx* c, uint32_t windows, uint32_t frames, bool p
     double poolLong = 2.4, wideLoad = 1.1, poolSlots = 4096.0, wideMt = 1.2, narrowSlots = 3500.0;
     if (const char* e = getenv("CRT_PLAN_NARROW_SLOTS")) narrowSlots = atof(e);
     const double K = (double)windows;
+    // machine time of one window's pool wavefront of a tile, per unit of its cost: from the measured machine time per window when the measuring launch
+    // oversubscribed the chip (adopt_job_costs), else from the wavefront durations (which then ran without much competition)
+    double costSum = 0; for (uint32_t v : c->jobCost) costSum += (double)v;
+    const double perCost = (c->poolWindowTicks > 0 && costSum > 0) ? c->poolWindowTicks / costSum : 1.0 / poolSlots;
     // machine time (ticks) of tile cost v in the cheapest class that lasts <= T; cls: 0 pool, 1 wide, 2 + k narrow (kLatLanes[k])
     auto cheapest = [&](double v, double T, int* cls) -> double {
-        if (pool && poolLong * v <= T) { *cls = 0; return K * v / poolSlots; }
-        if (wideLoad * v <= T) { *cls = 1; return K * wideMt * v / poolSlots; }
+        if (pool && poolLong * v <= T) { *cls = 0; return K * v * perCost; }
+        if (wideLoad * v <= T) { *cls = 1; return K * wideMt * v * perCost; }
         int k = 1; while (k < 6 && kLatG[k] * v > T) k++;
         *cls = 2 + k; return K * (64.0 / kLatLanes[k]) * kLatG[k] * v / narrowSlots;
     };
@@ -1135,14 +1158,14 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         bool wantJobCost = false;
         if (nf > 64u && !c->cfg.collectStats) {
             if (c->jobCostPending && hipEventQuery(c->jobCostCopied) == hipSuccess) { c->jobCostPending = false; if ((r = adopt_job_costs(c))) return r; HIPCK(c, hipStreamWaitEvent(st, c->orderReady, 0)); }
-            wantJobCost = !c->jobCostValid && !c->jobCostPending && nf >= 128u;       // (the pool records full 128-stream wavefronts only)
+            wantJobCost = !c->jobCostValid && !c->jobCostPending && nf >= 128u;       // (a pool launch records full 128-stream wavefronts only)
             if (wantJobCost) {
                 if (!c->dJobCost) {
-                    HIPCK(c, hipMalloc((void**)&c->dJobCost, (size_t)c->tileCount * 4));
-                    HIPCK(c, hipHostMalloc((void**)&c->hJobCost, (size_t)c->tileCount * 4, hipHostMallocDefault));
+                    HIPCK(c, hipMalloc((void**)&c->dJobCost, job_cost_bytes(c)));
+                    HIPCK(c, hipHostMalloc((void**)&c->hJobCost, job_cost_bytes(c), hipHostMallocDefault));
                     HIPCK(c, hipEventCreateWithFlags(&c->jobCostCopied, hipEventDisableTiming));
                 } else HIPCK(c, hipStreamWaitEvent(st, c->jobCostCopied, 0));      // behind an earlier measurement that a camera change abandoned
-                HIPCK(c, hipMemsetAsync(c->dJobCost, 0, (size_t)c->tileCount * 4, st));
+                HIPCK(c, hipMemsetAsync(c->dJobCost, 0, job_cost_bytes(c), st));
             }
         }
         HIPCK(c, hipEventRecord(ev.a, st));
@@ -1153,9 +1176,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         // threshold sits at the low end of that range.
         // With the tile costs known (most expensive first + split, see split_point) the pool is never slower than one stream per lane from ~12 windows of 720p on
         // (tools/split_probe.py: bunny 14 windows 57.8 against 59.6 ms, two-level scene 16 windows 79 against 94 ms, watch-tower 1080p 7 windows 155.6 against 161.1 ms).
-        // The job that MEASURES the tile costs runs the pool whenever it has at least two windows: split_point's two constants are calibrated on pool wavefronts
-        // under load (a render_tiles_kernel job inflates the cheap tiles' durations, not the expensive ones': its sum is no measure of the job's ideal length).
-        const uint64_t minWaves = c->poolMinWaves != 65000u ? c->poolMinWaves : (c->jobCostValid ? 43000u : (wantJobCost ? 1u : 65000u));
+        const uint64_t minWaves = c->poolMinWaves != 65000u ? c->poolMinWaves : (c->jobCostValid ? 43000u : 65000u);
         const bool pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * ((nf + 63u) / 64u) >= minWaves && (c->poolMinWaves == 0 || nf > 64u);
         hipError_t le;
         if (getenv("CRT_DEBUG_FAIL_LAUNCH")) le = hipErrorInvalidConfiguration;       // tests: the runtime refuses the launch
@@ -1165,6 +1186,13 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
             if (nf > 64u && c->jobCostValid) { if ((r = install_job_plan(c, windows, nf, pool))) return r; head = c->jobHead; jobBlocks = c->jobBlocks; }
             if (jobBlocks) HIPCK(c, hipStreamWaitEvent(st, c->jobDescReady, 0));
             le = hipSuccess;
+            unsigned long long* jobClk = nullptr;
+            if (wantJobCost) {                                                 // what adopt_job_costs needs to know about the measuring launch
+                jobClk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->dJobCost) + job_cost_clk_offset(c));
+                c->recPool = pool; c->recWindows = windows;
+                c->recWaves = pool ? c->tileCount * ((nf + crt_pool_streams(nf) - 1u) / crt_pool_streams(nf)) : c->tileCount * windows;
+                c->recResident = pool ? 4096u : 5120u;                            // 4 / 5 wavefronts per SIMD (render_pool_kernel / render_tiles_kernel)
+            }
             if (pool) {
                 void* scratch = (char*)slab + (size_t)windows * sample_bytes_per_window(c, passes);
                 hipStream_t st2 = st;
@@ -1172,12 +1200,12 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
                     // the expensive tiles first, through the block table, on this launch's stream; the pool for the rest on the next stream, released by the same start event
                     st2 = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
                     le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                           spp_first + f0 * passes, nf, passes, c->ldsBytes, 0, c->dJobDesc, jobBlocks, nullptr, 0u, st);
+                                           spp_first + f0 * passes, nf, passes, c->ldsBytes, 0, c->dJobDesc, jobBlocks, nullptr, 0u, nullptr, st);
                     if (le == hipSuccess) le = hipStreamWaitEvent(st2, ev.a, 0);
                 }
                 if (le == hipSuccess)
                     le = crt_launch_render_pool(&c->hScene, slab, scratch, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                                spp_first + f0 * passes, nf, passes, c->cfg.collectStats, jobBlocks ? head : 0u, wantJobCost ? c->dJobCost : nullptr, st2);
+                                                spp_first + f0 * passes, nf, passes, c->cfg.collectStats, jobBlocks ? head : 0u, wantJobCost ? c->dJobCost : nullptr, jobClk, st2);
                 if (jobBlocks && le == hipSuccess) {
                     if (c->splitEvents.size() < 32) { hipEvent_t e; le = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (le == hipSuccess) c->splitEvents.push_back(e); }
                     if (le == hipSuccess) { hipEvent_t e = c->splitEvents[c->splitSeq++ % c->splitEvents.size()]; le = hipEventRecord(e, st2); if (le == hipSuccess) le = hipStreamWaitEvent(st, e, 0); }
@@ -1186,7 +1214,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
                 const bool job = jobBlocks != 0u;
                 le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
                                        spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, job ? c->dJobDesc : blockDesc, job ? jobBlocks : nBlocks,
-                                       wantCost ? c->dTileCost : (wantJobCost ? c->dJobCost : nullptr), 0u, st);
+                                       wantCost ? c->dTileCost : (wantJobCost ? c->dJobCost : nullptr), 0u, jobClk, st);
             }
             if (jobBlocks && le == hipSuccess) c->splitLaunches++;
         }
@@ -1199,7 +1227,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         if (pool) c->poolLaunches++;
         HIPCK(c, hipEventRecord(ev.b, st));
         if (wantJobCost) {
-            HIPCK(c, hipMemcpyAsync(c->hJobCost, c->dJobCost, (size_t)c->tileCount * 4, hipMemcpyDeviceToHost, st));
+            HIPCK(c, hipMemcpyAsync(c->hJobCost, c->dJobCost, job_cost_bytes(c), hipMemcpyDeviceToHost, st));
             HIPCK(c, hipEventRecord(c->jobCostCopied, st));
             c->jobCostPending = true;
         }

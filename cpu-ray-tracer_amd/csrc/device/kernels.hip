@@ -67,11 +67,13 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                                                            const uint32_t* __restrict__ tileOrder,
                                                            uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                            uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t windows,
-                                                           const uint32_t* __restrict__ blockDesc, uint32_t* __restrict__ tileCost, uint32_t rankCount)
+                                                           const uint32_t* __restrict__ blockDesc, uint32_t* __restrict__ tileCost, uint32_t rankCount, unsigned long long* __restrict__ launchClk)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     const unsigned long long clk0 = (COUNT || tileCost) ? wall_clock64() : 0ull;
+    // a job that measures: when did the first and the last wavefront of the launch start (the host derives the launch's machine time from it, abi.cpp adopt_job_costs)
+    if (launchClk && lane == 0) { atomicMax(&launchClk[0], ~clk0); atomicMax(&launchClk[1], clk0); }
     // block -> tile.  The kernel's duration is set by its most expensive tiles (one serial RNG stream per lane), so the host
     // lists the tiles whose pixels can see the meshes FIRST (tileOrder): the dispatcher starts them first and they are dealt
     // round-robin over the 8 XCDs / 256 CUs instead of piling up on the XCDs that own the image rows of the model.  The
@@ -463,6 +465,8 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 
     // what this tile cost (100 MHz wall clock ticks; the longest of its wavefronts): the host's latency mode sizes the next launch's wavefronts with it
     if (tileCost && lane == 0) atomicMax(&tileCost[tl], (uint32_t)(wall_clock64() - clk0));
+    // ... and how much of this wavefront ran after the launch's last wavefront had started (the launch's drain: abi.cpp adopt_job_costs)
+    if (launchClk && lane == 0) { const unsigned long long now = wall_clock64(), last = __hip_atomic_load(&launchClk[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), from = last > clk0 ? last : clk0; if (now > from) atomicAdd(&launchClk[2], now - from); }
     if (COUNT && tileClocks && lane == 0 && windows == 1u) {                 // instrumentation build only: per-tile wall time + loop trips
         tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
         tileClocks[2 * tl + 1] = trips;
@@ -839,7 +843,7 @@ extern "C" hipError_t crt_launch_check_reciprocals(unsigned long long* out, hipS
 // blockDesc / nBlocks: block table (see the kernel; the launch renders exactly the table's blocks), else nullptr / 0; tileCost: nullptr or one uint32 per tile, atomicMax'ed
 extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                         uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
-                                        uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, const uint32_t* blockDesc, uint32_t nBlocks, uint32_t* tileCost, uint32_t rankCount, hipStream_t stream)
+                                        uint32_t frames, uint32_t passes, uint32_t ldsBytes, int collectStats, const uint32_t* blockDesc, uint32_t nBlocks, uint32_t* tileCost, uint32_t rankCount, unsigned long long* launchClk, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
     const uint32_t windows = (frames + 63u) / 64u;                      // one 64-lane wavefront per (tile, 64-frame window)
@@ -848,7 +852,7 @@ extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::C
     if (blockDesc && (tileCount > 0x10000u || windows > 64u)) return hipErrorInvalidValue;
     if (rankCount == 0u || rankCount > tileCount) rankCount = tileCount;          // the first rankCount tiles of the order only (all windows)
     dim3 grid(blockDesc ? nBlocks : rankCount * windows), block(64);
-#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows, blockDesc, tileCost, rankCount)
+#define CRT_LAUNCH(K, C) hipLaunchKernelGGL((crt::render_tiles_kernel<K, C>), grid, block, ldsBytes + 15u * 64u * 4u /* throughput-factor columns */, stream, *sc, (float4*)slab, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, windows, blockDesc, tileCost, rankCount, launchClk)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH(0, true); else CRT_LAUNCH(0, false); }
     else { if (collectStats) CRT_LAUNCH(1, true); else CRT_LAUNCH(1, false); }
 #undef CRT_LAUNCH

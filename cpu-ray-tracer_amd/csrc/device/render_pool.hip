@@ -67,7 +67,7 @@ template <int KIND, bool COUNT, int S, int SETS>
 __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
                                                              unsigned long long* __restrict__ tileClocks, const uint32_t* __restrict__ tileOrder,
                                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
-                                                             uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t groups, uint32_t rankFirst, uint32_t* __restrict__ tileCost)
+                                                             uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t groups, uint32_t rankFirst, uint32_t* __restrict__ tileCost, unsigned long long* __restrict__ launchClk)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
     const unsigned long long tl0 = wall_clock64();
 #endif
     const unsigned long long clk0 = (COUNT || tileCost) ? wall_clock64() : 0ull;
+    if (launchClk && lane == 0) { atomicMax(&launchClk[0], ~clk0); atomicMax(&launchClk[1], clk0); }     // first / last wavefront start of a measuring job (abi.cpp adopt_job_costs)
     // block -> (tile rank, group of S frames), rank-major: all groups of the expensive tiles (listed first by the host) are dispatched first;
     // rankFirst > 0: the tiles before it in the order are rendered by a concurrent render_tiles_kernel launch (a split job, abi.cpp)
     const uint32_t rank0 = blockIdx.x / groups, grp = blockIdx.x - rank0 * groups, rank = rank0 + rankFirst;
@@ -522,6 +523,8 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
     // what this tile costs (100 MHz ticks): this wavefront's duration per 64 streams (close to what the tile's one-stream-per-lane wavefront takes on an idle chip);
     // full groups only — a wavefront with fewer streams than S runs them less densely.  The host orders and plans later jobs with it (abi.cpp plan_job).
     if (tileCost && lane == 0 && nStreams == (uint32_t)S) atomicMax(&tileCost[tl], (uint32_t)((wall_clock64() - clk0) * 64ull / (uint32_t)S));
+    // ... and how much of this wavefront ran after the launch's last wavefront had started (the launch's drain: abi.cpp adopt_job_costs)
+    if (launchClk && lane == 0) { const unsigned long long now = wall_clock64(), last = __hip_atomic_load(&launchClk[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), from = last > clk0 ? last : clk0; if (now > from) atomicAdd(&launchClk[2], now - from); }
     if (COUNT && tileClocks && lane == 0 && groups == 1u) {                     // instrumentation: per-tile wall time + loop trips (one group per tile only)
         tileClocks[2 * tl] = wall_clock64() - clk0;        // 100 MHz constant clock
         tileClocks[2 * tl + 1] = trips;
@@ -561,7 +564,7 @@ extern "C" size_t crt_debug_pool_timeline(unsigned long long* out, size_t cap)  
 #endif
 extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, void* facScratch, crt::Counters* counters, unsigned long long* tileClocks, const uint32_t* tileOrder,
                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t sppFirst,
-                                             uint32_t frames, uint32_t passes, int collectStats, uint32_t rankFirst, uint32_t* tileCost, hipStream_t stream)
+                                             uint32_t frames, uint32_t passes, int collectStats, uint32_t rankFirst, uint32_t* tileCost, unsigned long long* launchClk, hipStream_t stream)
 {
     if (tileCount == 0 || frames == 0) return hipSuccess;
     if (!sc->ref16ok) return hipErrorInvalidValue;                              // the host launches render_tiles_kernel for such scenes
@@ -577,7 +580,7 @@ extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, v
 #endif
     const uint32_t sets = S == 64u ? 1u : (uint32_t)CRT_POOL_SETS;
     const uint32_t ldsBytes = crt_pool_lds_bytes(sc->stackDepth, S, sets);
-#define CRT_LAUNCH(K, C, SS, NS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS, NS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups, rankFirst, tileCost)
+#define CRT_LAUNCH(K, C, SS, NS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS, NS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups, rankFirst, tileCost, launchClk)
 #define CRT_LAUNCH_S(K, C) do { if (S == 64u) CRT_LAUNCH(K, C, 64, 1); else CRT_LAUNCH(K, C, CRT_POOL_STREAMS, CRT_POOL_SETS); } while (0)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH_S(0, true); else CRT_LAUNCH_S(0, false); }
     else { if (collectStats) CRT_LAUNCH_S(1, true); else CRT_LAUNCH_S(1, false); }
