@@ -58,3 +58,24 @@ def test_camera_change_and_frame_count_change_restart_the_measurement(crt, orc, 
             ctx.clear(); ctx.render(1, frames, 1); ctx.sync()
             got = ctx.accumulator()
             assert np.array_equal(got[mask], want[mask]) and not got[~mask].any(), (k, frames)
+
+
+def test_mixed_sequence_of_launch_shapes_and_camera_moves(crt, orc):
+    """The scheduling layer keeps state between calls (tile costs, block tables, plans, the tuner's stages): a caller that mixes single-window renders, jobs of
+    different lengths and passes, camera moves and timing reads must get the reference's pixels from every call."""
+    W, H = 96, 64
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o.renderer_init(W, H)
+    ctx = crt.Context(W, H); hs.upload(ctx)
+    rng = np.random.default_rng(7)
+    cams = [((0.0, 0.0, -2.0), (0.0, 0.0, -1.0)), ((0.5, 0.2, -1.6), (0.0, -0.3, 1.0)), ((-0.7, 0.1, -1.2), (0.0, -0.5, 1.5))]
+    cam = cams[0]
+    for step in range(26):
+        if step in (9, 17): cam = cams[1 + (step > 9)]; ctx.set_camera_state(*cam)
+        frames = int(rng.choice([1, 7, 16, 64, 64, 64, 130, 192, 256, 320]))
+        passes = int(rng.choice([1, 1, 1, 2]))
+        ctx.clear(); ctx.render(1, frames, passes); ctx.sync()
+        if step % 5 == 4: ctx.timing()
+        o.set_camera_state(*cam); o.clear(); o.set_spp(1); o.set_params(5, passes); o.render(frames, 4)
+        assert np.array_equal(ctx.accumulator(), o.accumulator()), (step, frames, passes)
