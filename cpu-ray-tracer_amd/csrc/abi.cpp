@@ -1077,6 +1077,7 @@ static void plan_job(const crt_ctx* c, uint32_t windows, uint32_t frames, bool p
             for (uint32_t b0 = 0; b0 < fw; b0 += L) table.push_back(block_desc(c->jobOrder[r], b0, L, w));
         }
     }
+    if (table.size() > (4u << 20)) { table.clear(); *head = 0; return; }          // (never seen: the machine-time bound keeps narrow tiles few; a plain launch is always valid)
     *head = pool ? h : 0u;
 }
 
