@@ -91,6 +91,7 @@ struct crt_ctx {
     // (HIP event durations of the launches themselves; identical pixels whatever the table).
     static constexpr int kLatStages = 6;       // (the bunny settles by stage 3, the two-level scene still gains at 5; bolder aims do not get lower: DESIGN.md §5)
     double tuneMs[kLatStages + 1] = {}; int tuneCount[kLatStages + 1] = {};
+    hipEvent_t lastRenderEnd = nullptr;   // end event of the most recent render launch (owned by the timing lists)
     int latStage = 0;              // stage of the table on the device (0: none yet)
     int latBest = 0;               // fastest stage so far
     bool latDone = false;          // all stages measured, the fastest one's table is (being) installed
@@ -1138,7 +1139,10 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         if ((r = take_event(c, c->evRender, &ev))) return r;
         // latency mode of a single-window launch (render_tiles_kernel): one wavefront per tile, or the current block table (see next_block_table)
         const uint32_t* blockDesc = nullptr; uint32_t nBlocks = 0; bool wantCost = false;
-        if (nf <= 64u && nf >= 8u && !c->cfg.collectStats && c->tileCount <= 0x10000u && !getenv("CRT_LAT_OFF")) {
+        // ... only when the GPU is idle at submission: a caller that queues launch after launch wants throughput, and narrow wavefronts buy latency with issue
+        // slots (56 queued single-window calls: 6.4 ms each with one wave per tile, 12.4 ms with the tuned table)
+        const bool gpuIdle = !c->lastRenderEnd || hipEventQuery(c->lastRenderEnd) == hipSuccess;
+        if (nf <= 64u && nf >= 8u && gpuIdle && !c->cfg.collectStats && c->tileCount <= 0x10000u && !getenv("CRT_LAT_OFF")) {
             if (c->costPending && hipEventQuery(c->costCopied) == hipSuccess) { c->costPending = false; harvest_tuning(c); if ((r = next_block_table(c))) return r; }
             const int stage = c->latStage;
             if (stage) { blockDesc = c->dBlockDesc; nBlocks = c->nBlocks; HIPCK(c, hipStreamWaitEvent(st, c->descReady, 0)); }
@@ -1227,6 +1231,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         }
         if (pool) c->poolLaunches++;
         HIPCK(c, hipEventRecord(ev.b, st));
+        c->lastRenderEnd = ev.b;
         if (wantJobCost) {
             HIPCK(c, hipMemcpyAsync(c->hJobCost, c->dJobCost, job_cost_bytes(c), hipMemcpyDeviceToHost, st));
             HIPCK(c, hipEventRecord(c->jobCostCopied, st));

@@ -7,6 +7,7 @@
 // CPU evaluation of the same expressions.  min/max follow the reference's std::min/std::max operand order.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include "layout.h"
 
@@ -234,7 +235,9 @@ __device__ __forceinline__ void hit_tri(rec4 a, rec4 b, rec4 c, f3 O, f3 D, Hit&
 
 // Quad::Intersect + Plane::Intersect (template/primitives.h:331-346, 107-111): the two analytic primitives FindNearest
 // tests before the acceleration structure (file_scene.cpp:170-175)
-__device__ __forceinline__ void hit_light_floor(const Scene& sc, f3 O, f3 D, Hit& h)
+// (the operands as values: render_pool_kernel reads them from the kernel-argument segment inside its passes instead of holding them in scalar registers)
+struct LightFloor { float lightInvT[12]; float lightSize; uint32_t lightAxis, floorAxisY; float floorN[3]; float floorD; };
+__device__ __forceinline__ void hit_light_floor(const LightFloor& sc, f3 O, f3 D, Hit& h)
 {
     // Scene::lightAxis / floorAxisY (set at upload): the quad's invT has an identity rotation block / the plane's normal is exactly
     // (0,1,0) — what FileScene and TLASFileScene always build (file_scene.cpp:15-19).  Then 1*x == x and the 0*x terms only add
@@ -267,6 +270,32 @@ __device__ __forceinline__ void hit_light_floor(const Scene& sc, f3 O, f3 D, Hit
         const float t = -num / den;
         if (t < h.t && t > 0) { h.t = t; h.objIdx = 1; }
     }
+}
+
+__device__ __forceinline__ void hit_light_floor(const Scene& sc, f3 O, f3 D, Hit& h)
+{
+    LightFloor lf;
+#pragma unroll
+    for (int i = 0; i < 12; i++) lf.lightInvT[i] = sc.lightInvT[i];
+    lf.lightSize = sc.lightSize; lf.lightAxis = sc.lightAxis; lf.floorAxisY = sc.floorAxisY;
+    lf.floorN[0] = sc.floorN[0]; lf.floorN[1] = sc.floorN[1]; lf.floorN[2] = sc.floorN[2]; lf.floorD = sc.floorD;
+    hit_light_floor(lf, O, D, h);
+}
+
+// Scene fields that only the shading passes need (the root's child pair, the camera, the light quad / floor plane: 50 dwords) are NOT held in scalar registers
+// across the render kernels' loops — with them render_pool_kernel spills ~50 SGPRs into VGPR lanes and pays v_readlane / v_writelane around every pass.  The passes re-read them from the
+// kernel-argument segment instead (the Scene block is the kernel's first argument: offset 0), through a pointer the optimiser cannot hoist: a few s_load_dwordx8/x16
+// per pass from the scalar cache.
+static_assert(offsetof(Scene, topLeft) == offsetof(Scene, camPos) + 12 && offsetof(Scene, bottomLeft) == offsetof(Scene, camPos) + 36 && offsetof(Scene, invW) == offsetof(Scene, camPos) + 48 && offsetof(Scene, invH) == offsetof(Scene, camPos) + 52, "camera block");
+static_assert(offsetof(Scene, lightSize) == offsetof(Scene, lightInvT) + 60 && offsetof(Scene, floorN) == offsetof(Scene, lightInvT) + 76 && offsetof(Scene, floorD) == offsetof(Scene, lightInvT) + 88 && offsetof(Scene, floorInvto) == offsetof(Scene, floorN) + 16, "light / floor block");
+static_assert(offsetof(Scene, floorAxisY) == offsetof(Scene, lightAxis) + 4 && offsetof(Scene, skyW) == offsetof(Scene, skyOffset) + 4 && offsetof(Scene, skyH) == offsetof(Scene, skyOffset) + 8, "flag / sky words");
+static_assert(offsetof(Material, absorption) == 8 && offsetof(Material, texOffset) == 20 && offsetof(Material, texW) == 24 && offsetof(Material, texH) == 28, "Material words");
+typedef const float __attribute__((address_space(4)))* kernarg_f;
+__device__ __forceinline__ kernarg_f scene_floats(size_t byteOffset)
+{
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + byteOffset;
+    asm volatile("" : "+s"(p));
+    return (kernarg_f)p;
 }
 
 // BLASBVH::Intersect's ray transform (infra/blas_bvh.cpp:376-381): invT rows, SSE summation order (x+y)+(z+w) / (x+y)+z

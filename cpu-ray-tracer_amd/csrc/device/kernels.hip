@@ -115,17 +115,14 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 #define CRT_STAMP(var)
 #endif
     const uint32_t items = 256u * passes;                                     // (pixel, pass) pairs in stream order
-    const f3 camPos = mk3(sc.camPos[0], sc.camPos[1], sc.camPos[2]);
-    const f3 TL = mk3(sc.topLeft[0], sc.topLeft[1], sc.topLeft[2]);
-    const f3 TR = mk3(sc.topRight[0], sc.topRight[1], sc.topRight[2]);
-    const f3 BL = mk3(sc.bottomLeft[0], sc.bottomLeft[1], sc.bottomLeft[2]);
+    const f3 nil3 = mk3(0.0f, 0.0f, 0.0f);                                    // placeholder of values no lane reads (the camera is read where a primary ray is generated)
 
     bool live = lane < frames;
     uint64_t liveMask = __builtin_amdgcn_ballot_w64(live);                    // lanes whose stream still has pixels to render
     uint32_t seed = init_seed(tx + ty * (uint32_t)sc.W + (sppFirst + (laneBase + lane) * passes) * 1799u);   // renderer.cpp:120
     uint32_t item = 0;
     // world-space ray of the current path segment, its nearest hit so far, path state
-    f3 O = camPos, D = camPos, rD = camPos; bool inside = false; int depth = 0;
+    f3 O = nil3, D = nil3, rD = nil3; bool inside = false; int depth = 0;
     Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
     // throughput factors of depths 0..4 (albedo*medium*... of each bounce, multiplied on unwind): written once per bounce and read once
     // per path, so they live in a per-lane LDS column behind the traversal stack (component j of depth k at fst[(3k + j) * 64]) instead
@@ -133,7 +130,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
     float* fst = reinterpret_cast<float*>(lds + sc.stackDepth * 64u + lane);
     // traversal state; (tO, tD, trD) = ray in the space of the structure being walked (object space inside a BLAS)
     uint32_t cur = kRefDone, sp = 0;
-    f3 tO = camPos, tD = camPos, trD = camPos;
+    f3 tO = nil3, tD = nil3, trD = nil3;
     bool rayFinite = true;                                                    // all of trD finite -> v_min/v_max slab test is exact
     bool fresh = true;                                                        // true: SHADE phase must generate a primary ray
     rec4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;                        // pre-loaded record of `cur`
@@ -188,13 +185,17 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
             // is ONE site, and the new ray's reciprocal direction, quad / plane tests and root step are ONE site.  Every lane
             // still evaluates exactly the reference's expressions in the reference's order.
             // stage 1: what did FindNearest return (renderer.cpp:52-55, 69)
+            // (Scene fields only this phase needs are read from the kernel-argument segment here instead of living in scalar registers across the loop: dev_common.h scene_floats)
+            const kernarg_f cam = scene_floats(offsetof(Scene, camPos));          // camPos, topLeft, topRight, bottomLeft, invW, invH
+            const f3 camPos = mk3(cam[0], cam[1], cam[2]);
             const bool first = fresh;                                             // no path yet: only generate the first primary ray
             const bool miss = !first && h.objIdx == -1;                           // -> GetSkyColor
             const bool stop = !first && h.objIdx != -1 && (depth >= sc.depthLimit || h.objIdx == 0);   // depth limit -> 0, light -> (24,24,22)
             const bool surf = !first && !miss && !stop;                           // floor or mesh: the path bounces
             if (!first && h.objIdx >= 2) cn.meshhits++;
             // stage 2: texture coordinates + surface data
-            float tu = 0, tv = 0; uint32_t tOff = sc.skyOffset; int tW = sc.skyW, tH = sc.skyH;
+            const kernarg_f sk = scene_floats(offsetof(Scene, skyOffset));        // skyOffset, skyW, skyH
+            float tu = 0, tv = 0; uint32_t tOff = asu(sk[0]); int tW = (int)asu(sk[1]), tH = (int)asu(sk[2]);
             f3 I = O, N = O, absorb = O; float refl = 0, refr = 0;
             if (miss) {                                                           // GetSkyColor, file_scene.cpp:142-154
                 const float phi = crt_atan2f(-D.z, D.x) + CRT_PI, theta = crt_acosf(-D.y);
@@ -206,15 +207,17 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
             if (surf) {
                 I = O + h.t * D;
                 if (h.objIdx == 1) {                                              // floor: Plane::GetNormal / GetUV (primitives.h:112-133)
-                    N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
+                    const kernarg_f fl = scene_floats(offsetof(Scene, floorN));     // floorN[3], floorD, floorInvto
+                    const kernarg_f fm = scene_floats(offsetof(Scene, floorMat));   // Material: reflectivity, refractivity, absorption[3], texOffset, texW, texH
+                    N = mk3(fl[0], fl[1], fl[2]);
                     if (N.y == 1) {
                         float u = I.x, v = I.z;
-                        u *= sc.floorInvto; v *= sc.floorInvto;
+                        u *= fl[4]; v *= fl[4];
                         tu = u - __builtin_floorf(u); tv = v - __builtin_floorf(v);
                     }
-                    refl = sc.floorMat.reflectivity; refr = sc.floorMat.refractivity;
-                    absorb = mk3(sc.floorMat.absorption[0], sc.floorMat.absorption[1], sc.floorMat.absorption[2]);
-                    tOff = sc.floorMat.texOffset; tW = sc.floorMat.texW; tH = sc.floorMat.texH;
+                    refl = fm[0]; refr = fm[1];
+                    absorb = mk3(fm[2], fm[3], fm[4]);
+                    tOff = asu(fm[5]); tW = (int)asu(fm[6]); tH = (int)asu(fm[7]);
                 } else {                                                          // mesh: GetNormal / GetUV (bvh.cpp:290-305, blas_bvh.cpp:391-406)
                     const f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q0.w, q1.x, q1.y), n2 = mk3(q1.z, q1.w, q2.x);   // (q0..q3) = the hit's ShadeTri
                     const float w = 1 - h.u - h.v;
@@ -313,7 +316,8 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                 const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
                 const float jy = rnd(seed);                                       // pinned: first draw is the y jitter
                 const float jx = rnd(seed);
-                const float u = ((float)x + jx) * sc.invW, vv = ((float)y + jy) * sc.invH;
+                const f3 TL = mk3(cam[3], cam[4], cam[5]), TR = mk3(cam[6], cam[7], cam[8]), BL = mk3(cam[9], cam[10], cam[11]);
+                const float u = ((float)x + jx) * cam[12], vv = ((float)y + jy) * cam[13];
                 const f3 P = TL + u * (TR - TL) + vv * (BL - TL);
                 v = P - camPos; norm = true;
 #if defined(CRT_DUP) && CRT_DUP == 9
@@ -342,7 +346,16 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 #endif
                 cn.rays++;
                 h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
-                hit_light_floor(sc, O, D, h);
+                {
+                    const kernarg_f lp = scene_floats(offsetof(Scene, lightInvT));   // lightInvT[12] lightNrm[3] lightSize lightPos[3] floorN[3] floorD
+                    const kernarg_f ax = scene_floats(offsetof(Scene, lightAxis));   // lightAxis, floorAxisY
+                    LightFloor lf;
+#pragma unroll
+                    for (int i = 0; i < 12; i++) lf.lightInvT[i] = lp[i];
+                    lf.lightSize = lp[15]; lf.floorN[0] = lp[19]; lf.floorN[1] = lp[20]; lf.floorN[2] = lp[21]; lf.floorD = lp[22];
+                    lf.lightAxis = asu(ax[0]); lf.floorAxisY = asu(ax[1]);
+                    hit_light_floor(lf, O, D, h);
+                }
 #if defined(CRT_DUP) && CRT_DUP == 3
                 { Hit h2; h2.t = 1e34f; h2.u = 0; h2.v = 0; h2.objIdx = -1; h2.triIdx = -1; hit_light_floor(sc, lnd3(O), lnd3(D), h2); sink(h2.t); sink((float)h2.objIdx); }
 #endif
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                     // the root's two children travel in the kernel arguments (scalar registers): the first traversal step
                     // (bvh.cpp:244-257 / tlas_bvh.cpp:96-110 at the root, empty stack) happens here, at this phase's lane
                     // density, and a ray that misses both boxes never leaves the SHADE state
-                    const float* rp = sc.rootPair;
+                    const kernarg_f rp = scene_floats(offsetof(Scene, rootPair));
                     const rec4 a0 = {rp[0], rp[1], rp[2], rp[3]}, a1 = {rp[4], rp[5], rp[6], rp[7]};
                     const rec4 b0 = {rp[8], rp[9], rp[10], rp[11]}, b1 = {rp[12], rp[13], rp[14], rp[15]};
                     float d1, d2;

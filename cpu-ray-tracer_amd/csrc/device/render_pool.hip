@@ -100,10 +100,7 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
     uint32_t trips = 0;
     const uint32_t items = 256u * passes;                                        // (pixel, pass) pairs in stream order
     const uint32_t rowLen = 64u * passes;                                        // float4 per pixel row of the slab
-    const f3 camPos = mk3(sc.camPos[0], sc.camPos[1], sc.camPos[2]);
-    const f3 TL = mk3(sc.topLeft[0], sc.topLeft[1], sc.topLeft[2]);
-    const f3 TR = mk3(sc.topRight[0], sc.topRight[1], sc.topRight[2]);
-    const f3 BL = mk3(sc.bottomLeft[0], sc.bottomLeft[1], sc.bottomLeft[2]);
+    const f3 nil3 = mk3(0.0f, 0.0f, 0.0f);                                       // placeholder of values no lane reads
 
     // every stream starts in the END queue as "fresh": the pass only generates its first primary ray
     for (uint32_t s = lane; s < nStreams; s += 64u) {
@@ -121,7 +118,7 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
     Res R[SETS];
 #pragma unroll
     for (int k = 0; k < SETS; k++) {
-        R[k].res = false; R[k].sid = 0; R[k].cur = kRefDone; R[k].sp = 0; R[k].tO = R[k].tD = R[k].trD = camPos; R[k].rayFinite = true;
+        R[k].res = false; R[k].sid = 0; R[k].cur = kRefDone; R[k].sp = 0; R[k].tO = R[k].tD = R[k].trD = nil3; R[k].rayFinite = true;
         R[k].h.t = 1e34f; R[k].h.u = 0; R[k].h.v = 0; R[k].h.objIdx = -1; R[k].h.triIdx = -1;
         R[k].q0 = rec4{0, 0, 0, 0}; R[k].q1 = R[k].q0; R[k].q2 = R[k].q0; R[k].q3 = R[k].q0;
         R[k].stk = stk0 + (uint32_t)k * sc.stackDepth * 64u;
@@ -139,10 +136,19 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
             D = norm ? v * inv : v;
             rD = rcp_exact3(D);
             cn.rays++;
-            hit_light_floor(sc, O, D, nh);
+            {
+                const kernarg_f lp = scene_floats(offsetof(Scene, lightInvT));      // lightInvT[12] lightNrm[3] lightSize lightPos[3] floorN[3] floorD: one block of the Scene
+                const kernarg_f ax = scene_floats(offsetof(Scene, lightAxis));      // lightAxis, floorAxisY
+                LightFloor lf;
+#pragma unroll
+                for (int i = 0; i < 12; i++) lf.lightInvT[i] = lp[i];
+                lf.lightSize = lp[15]; lf.floorN[0] = lp[19]; lf.floorN[1] = lp[20]; lf.floorN[2] = lp[21]; lf.floorD = lp[22];
+                lf.lightAxis = asu(ax[0]); lf.floorAxisY = asu(ax[1]);
+                hit_light_floor(lf, O, D, nh);
+            }
             if (sc.rootIsPair) {
                 // bvh.cpp:244-257 / tlas_bvh.cpp:96-110 at the root with an empty stack, from the child pair in the kernel arguments
-                const float* rp = sc.rootPair;
+                const kernarg_f rp = scene_floats(offsetof(Scene, rootPair));
                 const rec4 a0 = {rp[0], rp[1], rp[2], rp[3]}, a1 = {rp[4], rp[5], rp[6], rp[7]};
                 const rec4 b0 = {rp[8], rp[9], rp[10], rp[11]}, b1 = {rp[12], rp[13], rp[14], rp[15]};
                 float d1, d2;
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
                 const bool act = lane < n;
                 const uint32_t s = act ? qEnd[(endH + lane) & kQueueMask] : 0u;
                 endH += n;
-                uint32_t meta = 0, seed = 0; int obj = -1; f3 D = camPos;
+                uint32_t meta = 0, seed = 0; int obj = -1; f3 D = nil3;
                 if (act) { meta = st[F_META * S + s]; seed = st[F_SEED * S + s]; obj = (int)(meta >> kMetaObjShift) - 1; D = mk3(stf[F_DX * S + s], stf[F_DY * S + s], stf[F_DZ * S + s]); }
                 const bool first = (meta & kMetaFresh) != 0u;
                 const int depth = (int)((meta >> kMetaDepthShift) & 7u);
@@ -363,7 +369,8 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
                 uint32_t skyTexel = 0u;
                 if (miss) {
                     const float phi = crt_atan2f(-D.z, D.x) + CRT_PI, theta = crt_acosf(-D.y);
-                    skyTexel = sc.texels[tex_index(sc.skyOffset, sc.skyW, sc.skyH, phi * CRT_INV2PI, theta * CRT_INVPI)];
+                    const kernarg_f sk = scene_floats(offsetof(Scene, skyOffset));   // skyOffset, skyW, skyH
+                    skyTexel = sc.texels[tex_index(asu(sk[0]), (int)asu(sk[1]), (int)asu(sk[2]), phi * CRT_INV2PI, theta * CRT_INVPI)];
                 }
                 bool gen = act && first;
                 size_t sampleAt = 0;
@@ -375,13 +382,17 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
                     item++;
                     gen = item < items;                                            // else: the stream has rendered its 256 pixels
                 }
+                // the camera (camPos, topLeft, topRight, bottomLeft: 12 floats of the Scene block) is read here, not held in registers across the loop
+                const kernarg_f cam = scene_floats(offsetof(Scene, camPos));
+                const f3 camPos = mk3(cam[0], cam[1], cam[2]);
                 f3 v = camPos;
                 if (gen) {                                                         // ProcessTile + Camera::GetPrimaryRay (renderer.cpp:125-126, camera.h:23-30)
                     const uint32_t pix = (passes == 1u) ? item : item / passes;
                     const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
                     const float jy = rnd(seed);                                    // pinned: first draw is the y jitter
                     const float jx = rnd(seed);
-                    const float u = ((float)x + jx) * sc.invW, vv = ((float)y + jy) * sc.invH;
+                    const float u = ((float)x + jx) * cam[12], vv = ((float)y + jy) * cam[13];     // invW, invH follow the camera in the Scene block
+                    const f3 TL = mk3(cam[3], cam[4], cam[5]), TR = mk3(cam[6], cam[7], cam[8]), BL = mk3(cam[9], cam[10], cam[11]);
                     const f3 P = TL + u * (TR - TL) + vv * (BL - TL);
                     v = P - camPos;
                     cn.primary++;
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
                 const bool act = lane < n;
                 const uint32_t s = act ? qBnc[(bncH + lane) & kQueueMask] : 0u;
                 bncH += n;
-                f3 O = camPos, D = camPos; float ht = 0, hu = 0, hv = 0; int obj = 1; uint32_t tri = 0, seed = 0, meta = 0;
+                f3 O = nil3, D = nil3; float ht = 0, hu = 0, hv = 0; int obj = 1; uint32_t tri = 0, seed = 0, meta = 0;
                 if (act) {
                     tri = st[F_TRI * S + s];
                     O = mk3(stf[F_OX * S + s], stf[F_OY * S + s], stf[F_OZ * S + s]);
@@ -428,15 +439,17 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
                 if (act) {
                     I = O + ht * D;
                     if (obj == 1) {                                                // floor: Plane::GetNormal / GetUV (primitives.h:112-133)
-                        N = mk3(sc.floorN[0], sc.floorN[1], sc.floorN[2]);
+                        const kernarg_f fl = scene_floats(offsetof(Scene, floorN));      // floorN[3], floorD, floorInvto
+                        const kernarg_f fm = scene_floats(offsetof(Scene, floorMat));    // Material: reflectivity, refractivity, absorption[3], texOffset, texW, texH
+                        N = mk3(fl[0], fl[1], fl[2]);
                         if (N.y == 1) {
                             float u = I.x, vv = I.z;
-                            u *= sc.floorInvto; vv *= sc.floorInvto;
+                            u *= fl[4]; vv *= fl[4];
                             tu = u - __builtin_floorf(u); tv = vv - __builtin_floorf(vv);
                         }
-                        refl = sc.floorMat.reflectivity; refr = sc.floorMat.refractivity;
-                        absorb = mk3(sc.floorMat.absorption[0], sc.floorMat.absorption[1], sc.floorMat.absorption[2]);
-                        tOff = sc.floorMat.texOffset; tW = sc.floorMat.texW; tH = sc.floorMat.texH;
+                        refl = fm[0]; refr = fm[1];
+                        absorb = mk3(fm[2], fm[3], fm[4]);
+                        tOff = asu(fm[5]); tW = (int)asu(fm[6]); tH = (int)asu(fm[7]);
                     } else {                                                       // mesh: GetNormal / GetUV (bvh.cpp:290-305, blas_bvh.cpp:391-406)
                         const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
                         const float w = 1 - hu - hv;
