@@ -1496,6 +1496,28 @@ extern "C" int crt_debug_check_reciprocals(crt_ctx* c, uint64_t* out)
     return CRT_OK;
 }
 
+// tests (no GPU needed): the planner's decision for given tile costs — plan_job on a context that holds nothing but the costs.  table[] receives the block
+// descriptors (tile | first frame << 16 | log2(lanes) << 22 | window << 25), order[] the dispatch order, *head the number of leading tiles of it that go to the table
+// when the rest goes to the pool.  Returns the number of blocks, or a negative error code.
+extern "C" int crt_debug_plan_job(const uint32_t* cost, uint32_t n, uint32_t windows, uint32_t frames, int pool, double poolWindowTicks,
+                                  uint32_t* table, uint32_t tableCap, uint32_t* head, uint32_t* order)
+{
+    if (!cost || !n || !table || !head || !order) return CRT_ERR_INVALID;
+    crt_ctx c;
+    c.tileCount = n; c.jobCostValid = true; c.poolWindowTicks = poolWindowTicks;
+    c.streams.assign(2, nullptr);
+    c.jobCost.assign(cost, cost + n);
+    c.jobOrder.resize(n);
+    for (uint32_t i = 0; i < n; i++) c.jobOrder[i] = i;
+    std::stable_sort(c.jobOrder.begin(), c.jobOrder.end(), [&](uint32_t a, uint32_t b) { return c.jobCost[a] > c.jobCost[b]; });
+    std::vector<uint32_t> t; uint32_t h = 0;
+    plan_job(&c, windows, frames, pool != 0, t, &h);
+    c.streams.clear();
+    if (t.size() > tableCap) return CRT_ERR_INVALID;
+    memcpy(table, t.data(), t.size() * 4); memcpy(order, c.jobOrder.data(), (size_t)n * 4); *head = h;
+    return (int)t.size();
+}
+
 // diagnostics (tools/latency_probe.py): the tile costs the last recording single-window launch left on the device (100 MHz ticks, longest wavefront per tile)
 extern "C" int crt_debug_tile_costs(crt_ctx* c, uint32_t* out)
 {

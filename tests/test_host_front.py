@@ -212,3 +212,58 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
                 text = open(os.path.join(root, f), errors="replace").read()
                 assert "crt_oracle" not in text and "import orc" not in text and "oracle/" not in text.replace("oracle/_ref", ""), os.path.join(root, f)
+
+
+def _plan(crt, cost, windows, frames, pool, window_ticks=0.0):
+    L = crt.lib()
+    L.crt_debug_plan_job.restype = C.c_int
+    L.crt_debug_plan_job.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    n = len(cost)
+    cost = np.ascontiguousarray(cost, np.uint32)
+    table = np.zeros(n * windows * 64, np.uint32); order = np.zeros(n, np.uint32); head = C.c_uint32(0)
+    k = L.crt_debug_plan_job(cost.ctypes.data, n, windows, frames, int(pool), float(window_ticks), table.ctypes.data, table.size, C.byref(head), order.ctypes.data)
+    assert k >= 0, k
+    t = table[:k]
+    return dict(tile=t & 0xffff, base=(t >> 16) & 63, lanes=1 << ((t >> 22) & 7), window=t >> 25, head=head.value, order=order)
+
+
+@pytest.mark.parametrize("seed,n,windows,frames,pool", [(1, 3600, 20, 1280, True), (2, 450, 20, 1280, False), (3, 3600, 5, 300, False), (4, 900, 3, 130, True),
+                                                        (5, 8040, 7, 448, True), (6, 64, 2, 128, False), (7, 3600, 64, 4096, True)])
+def test_job_planner_covers_every_stream_exactly_once(crt, seed, n, windows, frames, pool):
+    """abi.cpp plan_job (host logic, no GPU): whatever the tile costs, the block table names every (tile, window, frame) of its tiles exactly once, its tiles are
+    the leading ones of the cost order (the rest is the pool's), and a more expensive tile never gets wider wavefronts than a cheaper one."""
+    rng = np.random.default_rng(seed)
+    cost = (rng.pareto(1.2, n) * 2.0e4 + rng.integers(1000, 30000, n)).clip(0, 4.0e6).astype(np.uint32)     # heavy-tailed, like an image with one expensive object
+    for window_ticks in (0.0, float(cost.sum()) / 4096.0):
+        p = _plan(crt, cost, windows, frames, pool, window_ticks)
+        order = p["order"]
+        assert sorted(order.tolist()) == list(range(n)) and np.all(np.diff(cost[order].astype(np.int64)) <= 0)
+        if len(p["tile"]) == 0:
+            assert p["head"] == 0
+            continue
+        tiles = np.unique(p["tile"])
+        expect = order[:p["head"]] if pool else order
+        assert set(tiles.tolist()) == set(expect.tolist())
+        if pool: assert 0 < p["head"] < n
+        rank = np.empty(n, np.int64); rank[order] = np.arange(n)
+        lanes_of = {}
+        for t, b, l, w in zip(p["tile"].tolist(), p["base"].tolist(), p["lanes"].tolist(), p["window"].tolist()):
+            assert w < windows and b % l == 0
+            lanes_of.setdefault(t, l); assert lanes_of[t] == l                         # one width per tile
+        # coverage: per (tile, window) the wavefronts tile [0, frames of the window) without overlap
+        cover = np.zeros((n, windows, 64), np.int32)
+        for t, b, l, w in zip(p["tile"].tolist(), p["base"].tolist(), p["lanes"].tolist(), p["window"].tolist()):
+            cover[t, w, b:b + l] += 1
+        for w in range(windows):
+            fw = min(64, frames - 64 * w)
+            assert np.all(cover[tiles, w, :fw] == 1), w
+            if fw < 64: assert np.all(cover[tiles, w, ((fw + 63) // 64) * 64:] == 0)
+        assert cover.max() == 1
+        widths = np.array([lanes_of[t] for t in expect.tolist()])
+        assert np.all(np.diff(widths) >= 0)                                               # along the cost order wavefronts only get wider
+
+
+def test_job_planner_leaves_long_jobs_of_even_tiles_to_the_pool(crt):
+    cost = np.full(3600, 5000, np.uint32)
+    p = _plan(crt, cost, 64, 4096, True)
+    assert len(p["tile"]) == 0 and p["head"] == 0
