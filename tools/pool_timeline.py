@@ -9,7 +9,7 @@ crt = importlib.util.module_from_spec(spec); spec.loader.exec_module(crt)
 A = os.path.join(REPO, "assets")
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 xml = sys.argv[2] if len(sys.argv) > 2 else "bunny_scene.xml"; kind = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-os.environ["CRT_RENDER_KERNEL"] = "pool_always"
+os.environ.setdefault("CRT_RENDER_KERNEL", "pool_always")
 sc = crt.HostScene(os.path.join(A, "scenes", xml), kind, A)
 ctx = crt.Context(1280, 720); sc.upload(ctx)
 ctx.render(1, 64 * K, 1); ctx.sync(); ctx.clear(); ctx.render(1, 64 * K, 1); ctx.sync()
