@@ -220,6 +220,7 @@ def main():
         return
 
     ms_step = elapsed / args.steps * 1e3
+    coll_lib = "RCCL" if (dist is None or dist.get_backend() == "nccl") else dist.get_backend()          # (gloo only in one-GPU rehearsals of the N > 1 path)
     # Dominant kernel = render_tiles_kernel.  Every launch of it in this process (the warm-up job and the timed job) enters the
     # average, so that avg_launch_ms is the figure rocprofv3 --kernel-trace --stats reports for the same command; bytes = SURVEY 8(d)'s
     # per-ray / per-sample figures x the device counters of one step x the steps a launch covers.
@@ -263,8 +264,8 @@ def main():
                                "progressive render; the %d steps are one crt_render job (%d render kernel launch(es), a wavefront per (tile, 128 consecutive frames), "
                                "+ ordered accumulate), one sync at the end%s"
                                % (args.scene, "TLASFileScene" if args.kind else "FileScene", W, H, SPP, SPP, args.steps, launches,
-                                  "" if world == 1 else ("; every one of the %d ranks renders its own %d windows, ONE RCCL all-reduce of the float4 accumulator closes the job" % (world, args.steps)
-                                                         if args.split == "frames" else "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE RCCL %s of the float4 accumulator closes the job" % (world, collective["used"]))),
+                                  "" if world == 1 else ("; every one of the %d ranks renders its own %d windows, ONE %s all-reduce of the float4 accumulator closes the job" % (world, args.steps, coll_lib)
+                                                         if args.split == "frames" else "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE " + coll_lib + " %s of the float4 accumulator closes the job" % (world, collective["used"]))),
                    "latency_ms_single_step": round(single_ms, 3) if single_ms else None,
                    "collective": None if dist is None else collective["used"], "rccl_ranks": None if dist is None else dist.get_world_size(), "backend": None if dist is None else dist.get_backend(),
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
