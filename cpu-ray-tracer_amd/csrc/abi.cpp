@@ -795,6 +795,22 @@ static const uint32_t kLatLanes[7] = {64u, 32u, 16u, 8u, 4u, 2u, 1u};
 static const double kLatG[7] = {1.0, 0.93, 0.88, 0.79, 0.69, 0.57, 0.48};
 static int lat_index(uint32_t L) { int k = 0; while (k < 6 && kLatLanes[k] != L) k++; return k; }
 
+// one feedback step of the latency tuner for one tile: it ran `lanes`-wide wavefronts and its slowest one took `cost`; the widest width whose modelled duration meets T
+static uint8_t next_lanes(uint8_t lanes, uint32_t cost, double T)
+{
+    int k = lat_index(lanes); const double unit = (double)cost / kLatG[k];                     // the model's one-wave cost of this tile
+    while (k < 6 && unit * kLatG[k] > T) k++;                                                  // narrower until the model meets the aim
+    while (k > 0 && unit * kLatG[k - 1] <= 0.9 * T) k--;                                        // wider while twice as wide still makes it comfortably
+    return (uint8_t)kLatLanes[k];
+}
+// tests (no GPU needed): next_lanes for n tiles
+extern "C" int crt_debug_next_lanes(const uint8_t* lanes, const uint32_t* cost, uint32_t n, double T, uint8_t* out)
+{
+    if (!lanes || !cost || !out) return CRT_ERR_INVALID;
+    for (uint32_t i = 0; i < n; i++) { if (lanes[i] == 0 || lanes[i] > 64 || (64 % lanes[i]) != 0) return CRT_ERR_INVALID; out[i] = next_lanes(lanes[i], cost[i], T); }
+    return CRT_OK;
+}
+
 static int upload_block_table(crt_ctx* c, const std::vector<uint8_t>& lanes, const std::vector<uint32_t>& cost)
 {
     const uint32_t n = c->tileCount;
@@ -864,13 +880,7 @@ static int next_block_table(crt_ctx* c)
     } else {
         double aim = s == 0 ? 0.64 : 0.92;
         if (const char* e = getenv("CRT_LAT_AIM")) { const double v = atof(e); if (s > 0 && v > 0) aim = v; }
-        const double T = aim * (double)top;
-        for (uint32_t i = 0; i < n; i++) {
-            int k = lat_index(baseL[i]); const double unit = (double)baseC[i] / kLatG[k];     // the model's one-wave cost of this tile
-            while (k < 6 && unit * kLatG[k] > T) k++;                                          // narrower until the model meets the aim
-            while (k > 0 && unit * kLatG[k - 1] <= 0.9 * T) k--;                                // wider while twice as wide still makes it comfortably
-            L[i] = (uint8_t)kLatLanes[k];
-        }
+        for (uint32_t i = 0; i < n; i++) L[i] = next_lanes(baseL[i], baseC[i], aim * (double)top);
     }
     const int r = upload_block_table(c, L, baseC);
     if (r) return r;

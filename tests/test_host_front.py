@@ -267,3 +267,27 @@ def test_job_planner_leaves_long_jobs_of_even_tiles_to_the_pool(crt):
     cost = np.full(3600, 5000, np.uint32)
     p = _plan(crt, cost, 64, 4096, True)
     assert len(p["tile"]) == 0 and p["head"] == 0
+
+
+def test_latency_tuner_step_is_monotone_and_valid(crt):
+    """abi.cpp next_lanes (host logic, no GPU): widths stay powers of two that divide 64; a tile over the aim never gets wider, a tile far below it never narrower;
+    a higher cost never yields a wider wavefront than a lower one at the same width and aim."""
+    L = crt.lib()
+    L.crt_debug_next_lanes.restype = C.c_int
+    L.crt_debug_next_lanes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p]
+    rng = np.random.default_rng(11)
+    n = 4096
+    lanes = rng.choice(np.array([64, 32, 16, 8, 4, 2, 1], np.uint8), n)
+    cost = rng.integers(1, 4_000_000, n).astype(np.uint32)
+    for T in (1.0e5, 8.0e5, 2.0e6, 3.9e6):
+        out = np.zeros(n, np.uint8)
+        assert L.crt_debug_next_lanes(lanes.ctypes.data, cost.ctypes.data, n, float(T), out.ctypes.data) == 0
+        assert np.all(np.isin(out, [64, 32, 16, 8, 4, 2, 1]))
+        assert np.all(out[cost > T] <= lanes[cost > T])                    # over the aim: never wider
+        assert np.all(out[cost < 0.4 * T] >= lanes[cost < 0.4 * T])         # far below it: never narrower
+        for w in (64, 8, 1):                                                # same width, same aim: monotone in the cost
+            m = lanes == w
+            o = np.argsort(cost[m], kind="stable")
+            assert np.all(np.diff(out[m][o].astype(np.int32)) <= 0)
+    bad = np.array([3], np.uint8)
+    assert L.crt_debug_next_lanes(bad.ctypes.data, cost.ctypes.data, 1, 1.0, np.zeros(1, np.uint8).ctypes.data) != 0
