@@ -95,6 +95,7 @@ struct crt_ctx {
     int latStage = 0;              // stage of the table on the device (0: none yet)
     int latBest = 0;               // fastest stage so far
     bool latDone = false;          // all stages measured, the fastest one's table is (being) installed
+    bool latConfirming = false; std::vector<int> latQueue;      // after the last stage: the two fastest stages are timed once more
     bool latWarm = false;          // stage 0 has been measured once already (the first launch after an upload runs cold: it is measured twice)
     std::vector<uint8_t> latL[kLatStages + 1];          // lanes per wavefront of every tile, per stage ([0]: all 64)
     std::vector<uint32_t> latCost[kLatStages + 1];      // measured tile costs, per stage
@@ -768,7 +769,7 @@ static int update_tile_order(crt_ctx* c)
     }
     // a new camera / scene: the latency mode measures again (see next_block_table)
     for (int k = 0; k <= crt_ctx::kLatStages; k++) { c->tuneCount[k] = 0; c->tuneMs[k] = 0; }
-    c->latStage = 0; c->latBest = 0; c->latDone = false; c->latWarm = false; c->costPending = false;
+    c->latStage = 0; c->latBest = 0; c->latDone = false; c->latWarm = false; c->latConfirming = false; c->latQueue.clear(); c->costPending = false;
     first.insert(first.end(), rest.begin(), rest.end());
     c->jobCostValid = false; c->jobCostPending = false; c->planValid = false;
     { const int r = upload_tile_order(c, first); if (r) return r; }
@@ -862,13 +863,29 @@ static int next_block_table(crt_ctx* c)
         }
         if (s >= 1) last = true;
     }
-    if (last) {                                                           // install the fastest stage's table (stage 0 needs none)
-        c->latDone = true;
+    auto install = [&](int stage) -> int {                                  // the table of an earlier stage back onto the device (stage 0 needs none)
+        if (stage != 0 && stage != c->latStage) { const int r = upload_block_table(c, c->latL[stage], c->latCost[stage]); if (r) return r; }
+        c->latStage = stage; return 0;
+    };
+    auto fastest = [&](int except) { int b = -1; for (int k = 0; k <= K; k++) if (k != except && c->tuneCount[k] && (b < 0 || c->tuneMs[k] < c->tuneMs[b])) b = k; return b; };
+    auto finish = [&]() -> int {
+        c->latDone = true; c->latConfirming = false;
+        const int b = fastest(-1); c->latBest = b < 0 ? 0 : b;
         if (getenv("CRT_LAT_FORCE")) c->latBest = s;                       // diagnostics: keep the last table whatever its time
         if (getenv("CRT_LAT_VERBOSE")) { fprintf(stderr, "[crt] latency stages:"); for (int k = 0; k <= K; k++) if (c->tuneCount[k]) fprintf(stderr, " %d: %.2f ms", k, c->tuneMs[k]); fprintf(stderr, " -> %d\n", c->latBest); }
-        if (c->latBest != 0 && c->latBest != c->latStage) { const int b = c->latBest; const int r = upload_block_table(c, c->latL[b], c->latCost[b]); if (r) return r; }
-        c->latStage = c->latBest;
-        return 0;
+        return install(c->latBest);
+    };
+    if (c->latConfirming) {                                               // a confirmation launch of stage s has been timed (harvest_tuning keeps each stage's minimum)
+        if (!c->latQueue.empty()) c->latQueue.erase(c->latQueue.begin());
+        if (!c->latQueue.empty()) return install(c->latQueue.front());
+        return finish();
+    }
+    if (last) {
+        // every stage has ONE timing so far, and launch durations scatter by a few per cent: the two fastest stages run once more before the choice is final
+        const int a = fastest(-1), b2 = fastest(a);
+        if (getenv("CRT_LAT_FORCE") || a < 0 || b2 < 0) return finish();
+        c->latQueue = {a, b2}; c->latConfirming = true;
+        return install(a);
     }
     const int b = c->latBest;                                              // base: the fastest stage so far
     const std::vector<uint8_t>& baseL = c->latL[b]; const std::vector<uint32_t>& baseC = c->latCost[b];
