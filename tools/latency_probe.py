@@ -25,7 +25,7 @@ for pol in policies:
     stride = int(os.environ.get("PROBE_TILE_STRIDE", "1")); tiles = (W // 16) * (H // 16)      # (stride > 1: how does the mode behave with a lighter load)
     ctx = crt.Context(W, H, tile_stride=stride, tile_count=(tiles + stride - 1) // stride if stride > 1 else -1); sc.upload(ctx)
     ts = []
-    for i in range(18):
+    for i in range(24):
         ctx.clear(); ctx.sync(); t0 = time.perf_counter(); ctx.render(1, 64, 1); ctx.sync(); ts.append((time.perf_counter() - t0) * 1e3)
     acc = ctx.accumulator()
     cost = np.zeros((W // 16) * (H // 16), np.uint32)       # (a strided context fills only its first tiles)
