@@ -94,6 +94,44 @@ def cpu_baseline(scene_xml, kind, W, H, budget_s=float(os.environ.get("CRT_BENCH
             "ms_per_frame": round(dt / (frames + 1) * 1e3, 2)}
 
 
+def workload_text(scene, kind, W, H, spp, steps, launches, world, split, coll_lib, collective):
+    """config.workload of the output line (a plain function so that the N > 1 wording is testable without a GPU)"""
+    text = ("%s %s BVH-SAH path tracer, %dx%d, %d spp/step (passes=1, depthLimit=5); 1 step = %d frames = the next spp window of a "
+            "progressive render; the %d steps are one crt_render job (%d render kernel launch(es), a wavefront per (tile, 128 consecutive frames), "
+            "+ ordered accumulate), one sync at the end" % (scene, "TLASFileScene" if kind else "FileScene", W, H, spp, spp, steps, launches))
+    if world > 1 and split == "frames":
+        text += "; every one of the %d ranks renders its own %d windows, ONE %s all-reduce of the float4 accumulator closes the job" % (world, steps, coll_lib)
+    elif world > 1:
+        text += "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE %s %s of the float4 accumulator closes the job" % (world, coll_lib, collective)
+    return text
+
+
+def spawn_command(gpus, argv, port=None):
+    """`bench.py --gpus N` without an external launcher: the command that starts the N ranks (one per GPU) on this node"""
+    if port is None:
+        port = 29500 + (os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def choose_collective(dist, torch, device, wanted):
+    """The collective that closes a tile-split job, decided ONCE and identically on every rank before the warm-up: `reduce` is probed on a tiny tensor
+    (a backend may refuse it for device tensors — gloo rehearsals), the ranks agree on the outcome with an all_reduce(MIN) of a success flag."""
+    if wanted != "reduce":
+        return wanted
+    ok = 1
+    try:
+        probe = torch.ones(4, dtype=torch.float32, device=device)
+        dist.reduce(probe, dst=0, op=dist.ReduceOp.SUM)
+        if str(device) != "cpu":
+            torch.cuda.synchronize()
+    except RuntimeError:
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return "reduce" if int(flag.item()) == 1 else "all_reduce"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,26 +152,36 @@ def main():
     ap.add_argument("--no-single-render", action="store_true", help="skip the single-render latency measurement (three 64-frame renders on their own after the job)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no external launcher: start the N ranks ourselves — before anything in this process touches the GPU (no torch import yet) — and hand their exit code on;
+        # rank 0 of the children prints the one JSON line
+        import subprocess
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(spawn_command(args.gpus, sys.argv[1:])))
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1 or os.environ.get("CRT_BENCH_FORCE_DIST"):      # (FORCE_DIST: a one-rank RCCL rehearsal on a one-GPU box — init, reduce / all_reduce, barrier all run)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("CRT_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse the N > 1 code path on a one-GPU box
-        local_rank %= max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
+        local_rank %= max(torch.cuda.device_count(), 1)            # (device_count does not initialise the GPU)
         if backend == "nccl":
+            if not torch.cuda.is_available():
+                sys.exit("bench.py needs an MI355X: there is no CPU path for the product")
+            torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: there is no CPU path for the product")
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        sys.exit("bench.py needs an MI355X: there is no CPU path for the product (rank %d of %d)" % (rank, world))
     device = local_rank if world > 1 else 0
     torch.cuda.set_device(device)
 
@@ -160,7 +208,7 @@ def main():
     counts = {k: v / args.steps for k, v in sctx.counters().items()}
     sctx.close()
 
-    collective = {"used": args.reduce}
+    collective = {"used": args.reduce if dist is None else choose_collective(dist, torch, "cuda:%d" % device, args.reduce)}
 
     def run(n_steps):
         """n_steps steps = 64*n_steps frames submitted as one job: the back end renders up to 64 windows per render_tiles_kernel
@@ -171,11 +219,7 @@ def main():
         ctx.sync()
         if dist is not None:
             if collective["used"] == "reduce":
-                try:
-                    crt.reduce_accumulator(acc, dist, 0)
-                except RuntimeError:                     # a backend without reduce for device tensors (gloo rehearsals): all_reduce from now on
-                    collective["used"] = "all_reduce"
-                    crt.allreduce_accumulator(acc, dist)
+                crt.reduce_accumulator(acc, dist, 0)
             else:
                 crt.allreduce_accumulator(acc, dist)
             torch.cuda.synchronize()
@@ -260,12 +304,7 @@ def main():
         "ms_per_frame": round(ms_step / SPP, 5),
         "higher_is_better": True, "scaling": "weak" if args.split == "frames" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s %s BVH-SAH path tracer, %dx%d, %d spp/step (passes=1, depthLimit=5); 1 step = %d frames = the next spp window of a "
-                               "progressive render; the %d steps are one crt_render job (%d render kernel launch(es), a wavefront per (tile, 128 consecutive frames), "
-                               "+ ordered accumulate), one sync at the end%s"
-                               % (args.scene, "TLASFileScene" if args.kind else "FileScene", W, H, SPP, SPP, args.steps, launches,
-                                  "" if world == 1 else ("; every one of the %d ranks renders its own %d windows, ONE %s all-reduce of the float4 accumulator closes the job" % (world, args.steps, coll_lib)
-                                                         if args.split == "frames" else "; the image's tiles are dealt round-robin over %d ranks (tile ownership), ONE " + coll_lib + " %s of the float4 accumulator closes the job" % (world, collective["used"]))),
+        "config": {"workload": workload_text(args.scene, args.kind, W, H, SPP, args.steps, launches, world, args.split, coll_lib, collective["used"]),
                    "latency_ms_single_step": round(single_ms, 3) if single_ms else None,
                    "collective": None if dist is None else collective["used"], "rccl_ranks": None if dist is None else dist.get_world_size(), "backend": None if dist is None else dist.get_backend(),
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),

@@ -59,12 +59,27 @@ constexpr uint32_t kQueueMask = 127u;                            // queues are r
 #else
 #define CRT_PSTAMP(var)
 #endif
+#ifdef CRT_POOL_DENS
+// diagnostic build only (-DCRT_POOL_DENS, tools/pool_density.py): how often every section of the loop runs and with how many lanes, summed over all waves
+__device__ unsigned long long g_poolDens[32];
+#define CRT_DENS(i, v) (dens[i] += (uint32_t)(v))
+#define CRT_DENS_MASK(i, pred) (dens[i] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pred)))
+#else
+#define CRT_DENS(i, v)
+#define CRT_DENS_MASK(i, pred)
+#endif
 #ifdef CRT_POOL_TIMELINE
 // diagnostic build only (-DCRT_POOL_TIMELINE, tools/pool_timeline.py): start / end wall clock (100 MHz) and compute unit of every wavefront of the last launch
 __device__ unsigned long long* g_poolTimeline = nullptr;
 #endif
-template <int KIND, bool COUNT, int S, int SETS>
-__global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
+// Lane sets of the loop are explicit 64-bit scalar masks (mRes: lanes holding a resident stream; mNode / mTri / mTlas: what each resident lane is at) and a
+// per-lane predicate is `lane_in(mask)` = the mask used directly as the execution / select mask (amdgcn inverse ballot): no v_cndmask + v_cmp round trip per
+// ballot, and `resident` never has to be re-derived from lane state.
+__device__ __forceinline__ bool lane_in(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ uint32_t rank_in(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }   // set bits below this lane
+
+template <int KIND, bool COUNT, int S>
+__global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(const Scene sc, float4* __restrict__ slab, float* __restrict__ facScratch, Counters* __restrict__ counters,
                                                              unsigned long long* __restrict__ tileClocks, const uint32_t* __restrict__ tileOrder,
                                                              uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                              uint32_t sppFirst, uint32_t frames, uint32_t passes, uint32_t groups, uint32_t rankFirst, uint32_t* __restrict__ tileCost, unsigned long long* __restrict__ launchClk)
@@ -89,15 +104,23 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
     float* __restrict__ fac = facScratch + (size_t)blockIdx.x * (15u * (uint32_t)S);
 
     // `cur` and the stack entries of this kernel are 16-bit references (layout.h: ref16 — the children's are stored next to the 32-bit ones in
-    // every NodePair); 2 bytes per stack entry instead of 4 is what lets 128 parked streams + the stacks fit 4 waves per SIMD
-    uint16_t* stk0 = reinterpret_cast<uint16_t*>(lds) + lane;                    // traversal stack of a stream resident in this lane: entry i at stk[i * 64] (one stack per resident set)
-    uint32_t* st = lds + sc.stackDepth * 32u * (uint32_t)SETS;                   // parked stream state (behind SETS * stackDepth * 64 two-byte entries)
+    // every NodePair); 2 bytes per stack entry instead of 4 is what lets 128 parked streams + the stacks fit 4 waves per SIMD.
+    // Traversal stack of the stream resident in a lane: entry i (1 .. stackDepth) at LDS byte  2 * lane + 128 * i;  entry 0 is a dummy below the bottom, so the
+    // speculative read of the top and the dead store above it need no bounds logic, and the stack pointer IS the byte address of the top entry (`spB`).
+    char* const ldsB = reinterpret_cast<char*>(lds);
+    const uint32_t laneB = lane * 2u;
+    uint32_t* st = lds + (sc.stackDepth + 1u) * 32u;                             // parked stream state (behind (stackDepth + 1) * 64 two-byte entries)
     float* stf = reinterpret_cast<float*>(st);
     uint8_t* qEnd = reinterpret_cast<uint8_t*>(st + F_COUNT * S);
     uint8_t* qBnc = qEnd + 128, * qRdy = qEnd + 256;
+    auto stk_top = [&](uint32_t at) -> uint32_t { return *reinterpret_cast<const uint16_t*>(ldsB + at); };
+    auto stk_put = [&](uint32_t at, uint32_t v) { *reinterpret_cast<uint16_t*>(ldsB + at) = (uint16_t)v; };
 
     Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
     uint32_t trips = 0;
+#ifdef CRT_POOL_DENS
+    uint32_t dens[32]; for (int i = 0; i < 32; i++) dens[i] = 0;
+#endif
     const uint32_t items = 256u * passes;                                        // (pixel, pass) pairs in stream order
     const uint32_t rowLen = 64u * passes;                                        // float4 per pixel row of the slab
     const f3 nil3 = mk3(0.0f, 0.0f, 0.0f);                                       // placeholder of values no lane reads
@@ -110,21 +133,14 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
     }
     uint32_t endH = 0, endT = nStreams, bncH = 0, bncT = 0, rdyH = 0, rdyT = 0;  // queue heads / tails (wave-uniform)
 
-    // The streams resident in this lane: SETS of them (1, or 2 = "dual" mode).  With two sets the walk of set A runs while the record loads of set B
-    // fly and vice versa, so a wave hides its own load latency, and a wave's 128 streams can all be resident at once (no stream waits for a lane).
-    struct Res {
-        bool res; uint32_t sid, cur, sp; f3 tO, tD, trD; bool rayFinite; Hit h; rec4 q0, q1, q2, q3; uint16_t* stk;
-    };
-    Res R[SETS];
-#pragma unroll
-    for (int k = 0; k < SETS; k++) {
-        R[k].res = false; R[k].sid = 0; R[k].cur = kRefDone; R[k].sp = 0; R[k].tO = R[k].tD = R[k].trD = nil3; R[k].rayFinite = true;
-        R[k].h.t = 1e34f; R[k].h.u = 0; R[k].h.v = 0; R[k].h.objIdx = -1; R[k].h.triIdx = -1;
-        R[k].q0 = rec4{0, 0, 0, 0}; R[k].q1 = R[k].q0; R[k].q2 = R[k].q0; R[k].q3 = R[k].q0;
-        R[k].stk = stk0 + (uint32_t)k * sc.stackDepth * 64u;
-    }
-
-#define CRT_TOP() (r.stk[(r.sp ? r.sp - 1u : 0u) * 64u])
+    // The stream resident in this lane (if any: mRes).  Invariant at the top of a trip: a resident stream is walking (cur != done) — streams whose walk ended
+    // leave their lane in the trip that ended it, and only streams with a walk ahead are ever READY.
+    uint64_t mRes = 0ull;                                                        // lanes holding a stream
+    uint64_t mFinite = ~0ull;                                                    // ... whose reciprocal direction is finite in all components (v_min / v_max slab test is exact)
+    uint32_t sid = 0, cur = kRefDone, spB = laneB, metaLo = 0u;
+    f3 tO = nil3, tD = nil3, trD = nil3;
+    Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+    rec4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
 
     // ---- the start of a stream's next scene.FindNearest, shared by both shading passes: normalise, reciprocal direction, light quad,
     // floor plane, root step; parks the new ray and queues the stream (READY, or END / BOUNCE when the ray never enters the tree)
@@ -170,171 +186,175 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
             st[F_SEED * S + s] = seed; st[F_META * S + s] = meta | ((uint32_t)(nh.objIdx + 1) << kMetaObjShift);
             st[F_CUR * S + s] = ncur; st[F_PEND * S + s] = pend;
         }
-        // queue: the walk is needed only when the ray enters the tree; otherwise FindNearest is already over (renderer.cpp:52-55, 69)
+        // queue: the walk is needed only when the ray enters the tree; otherwise FindNearest is already over (renderer.cpp:52-55, 69).  Every set is the ballot of ONE
+        // comparison combined with scalar logic.
         const uint32_t depth = (meta >> kMetaDepthShift) & 7u;
-        const bool walk = act && ncur != kRefDone;
-        const bool toEnd = act && !walk && (nh.objIdx == -1 || nh.objIdx == 0 || (int)depth >= sc.depthLimit);
-        const bool toBnc = act && !walk && !toEnd;
-        const uint64_t mW = __builtin_amdgcn_ballot_w64(walk), mE = __builtin_amdgcn_ballot_w64(toEnd), mB = __builtin_amdgcn_ballot_w64(toBnc);
-        if (walk) qRdy[(rdyT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mW >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mW, 0u))) & kQueueMask] = (uint8_t)s;
-        if (toEnd) qEnd[(endT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mE >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mE, 0u))) & kQueueMask] = (uint8_t)s;
-        if (toBnc) qBnc[(bncT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u))) & kQueueMask] = (uint8_t)s;
+        const uint64_t mAct = __builtin_amdgcn_ballot_w64(act);
+        const uint64_t mW = mAct & __builtin_amdgcn_ballot_w64(ncur != kRefDone);
+        const uint64_t mStop = __builtin_amdgcn_ballot_w64((uint32_t)(nh.objIdx + 1) <= 1u) | __builtin_amdgcn_ballot_w64((int)depth >= sc.depthLimit);   // miss, light, or depth limit
+        const uint64_t mE = mAct & ~mW & mStop, mB = mAct & ~mW & ~mStop;
+        CRT_DENS(20, __popcll(mAct)); CRT_DENS(19, __popcll(mW));
+        if (lane_in(mW)) qRdy[(rdyT + rank_in(mW)) & kQueueMask] = (uint8_t)s;
+        if (lane_in(mE)) qEnd[(endT + rank_in(mE)) & kQueueMask] = (uint8_t)s;
+        if (lane_in(mB)) qBnc[(bncT + rank_in(mB)) & kQueueMask] = (uint8_t)s;
         rdyT += (uint32_t)__popcll(mW); endT += (uint32_t)__popcll(mE); bncT += (uint32_t)__popcll(mB);
+    };
+    // back to the world-space ray when a BLAS is finished (two-level scenes): the parked copy is the world-space ray
+    auto world_ray = [&]() {
+        tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
+        tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
+        trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
     };
 
 #ifdef CRT_POOL_STAMPS
     unsigned long long pst[5] = {0, 0, 0, 0, 0};
 #endif
-    // ---------------- D. walk: the phases of one resident set (TLAS leaf / NODE / TRI), on the records loaded by its previous trip ----------------
-    auto walk = [&](Res& r) {
-        const bool isNode = r.res && (KIND == 1 ? (((r.cur >> 15) ^ (r.cur >> 14)) & 1u) != 0u : (r.cur & kRef16TagMask) == kRef16Interior);
-        const bool isTri = r.res && r.cur != kRefDone && (r.cur & kRef16TagMask) == 0u;
-        const bool isTlas = (KIND == 1) && r.res && (r.cur & kRef16TagMask) == kRef16TlasLeaf;
-        const bool runNode = __builtin_amdgcn_ballot_w64(isNode) != 0ull, runTri = __builtin_amdgcn_ballot_w64(isTri) != 0ull;
-        const bool runTlas = (KIND == 1) && __builtin_amdgcn_ballot_w64(isTlas) != 0ull;
-        // The record loads issued at the end of the previous trip are first needed here.  Naming all four tuples in one
-        // empty asm keeps the register allocator from splitting a loaded tuple across the back-edge.
-        asm volatile("" : "+v"(r.q0), "+v"(r.q1), "+v"(r.q2), "+v"(r.q3));
-        if (KIND == 1 && runTlas && isTlas) {
-            // ---------------- TLAS leaf (infra/tlas_bvh.cpp:91-95) -> enter the BLAS (BLASBVH::Intersect, blas_bvh.cpp:376-381) ----------
-            if (COUNT) { cn.tlas++; cn.visits++; }
-            const f3 O = mk3(stf[F_OX * S + r.sid], stf[F_OY * S + r.sid], stf[F_OZ * S + r.sid]);
-            const f3 D = mk3(stf[F_DX * S + r.sid], stf[F_DY * S + r.sid], stf[F_DZ * S + r.sid]);
-            to_object_space(r.q0, r.q1, r.q2, O, D, r.tO, r.tD, r.trD);
-            r.rayFinite = finite3(r.trD);
-            r.stk[r.sp * 64u] = (uint16_t)kRef16Return; r.sp++;
-            const uint32_t next = asu(r.q3.y);                                     // Instance::rootRef16
-            if (COUNT && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
-            r.cur = next;
-        }
-        if (runNode) {
-            // ---------------- NODE phase (infra/bvh.cpp:244-257) ------------------------------------------------------------------------
-            const bool allFinite = __builtin_amdgcn_ballot_w64(isNode && !r.rayFinite) == 0ull;
-            if (isNode) {
-                if (COUNT) { if (KIND == 1 && (r.cur & kRef16TlasBit) != 0u) cn.tlas++; else cn.interior++; }
-                uint32_t top = CRT_TOP();                                          // speculative: lands during the slab arithmetic
-                float d1, d2;
-                if (allFinite) { d1 = box_fast(r.q0, r.q1, r.tO, r.trD, r.h.t); d2 = box_fast(r.q2, r.q3, r.tO, r.trD, r.h.t); }
-                else { d1 = box_exact(r.q0, r.q1, r.tO, r.trD, r.h.t); d2 = box_exact(r.q2, r.q3, r.tO, r.trD, r.h.t); }
-                const bool sw = d1 > d2;                                           // near child first (strict >: ties keep child 1)
-                const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
-                const uint32_t rn = sw ? asu(r.q3.w) : asu(r.q1.w), rf = sw ? asu(r.q1.w) : asu(r.q3.w);   // the children's ref16
-                r.stk[r.sp * 64u] = (uint16_t)rf;                                  // dead store unless `push`
-                const bool hitN = dn != 1e30f, push = hitN && df != 1e30f;
-                bool pop = !hitN && r.sp != 0u;
-                uint32_t next = hitN ? rn : (pop ? top : kRefDone);
-                r.sp = r.sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
-                if (KIND == 1 && next == kRef16Return) {                             // BLAS finished: back to the world-space ray, pop the TLAS entry below
-                    r.tO = mk3(stf[F_OX * S + r.sid], stf[F_OY * S + r.sid], stf[F_OZ * S + r.sid]);
-                    r.tD = mk3(stf[F_DX * S + r.sid], stf[F_DY * S + r.sid], stf[F_DZ * S + r.sid]);
-                    r.trD = mk3(stf[F_RX * S + r.sid], stf[F_RY * S + r.sid], stf[F_RZ * S + r.sid]);
-                    r.rayFinite = finite3(r.trD);
-                    pop = r.sp != 0u; top = CRT_TOP();
-                    next = pop ? top : kRefDone; r.sp -= pop ? 1u : 0u;
-                }
-                if (COUNT && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
-                r.cur = next;
-            }
-        }
-        if (runTri && isTri) {
-            // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:203-222, 232-243) -------------------------------
-            if (COUNT) cn.tri++;
-            uint32_t top = CRT_TOP();
-            hit_tri(r.q0, r.q1, r.q2, r.tO, r.tD, r.h);
-            const bool more = asu(r.q2.w) > 1u;                                    // the leaf's next LeafTri is the next index
-            bool pop = !more && r.sp != 0u;
-            uint32_t next = more ? r.cur + 1u : (pop ? top : kRefDone);
-            r.sp -= pop ? 1u : 0u;
-            if (KIND == 1 && next == kRef16Return) {
-                r.tO = mk3(stf[F_OX * S + r.sid], stf[F_OY * S + r.sid], stf[F_OZ * S + r.sid]);
-                r.tD = mk3(stf[F_DX * S + r.sid], stf[F_DY * S + r.sid], stf[F_DZ * S + r.sid]);
-                r.trD = mk3(stf[F_RX * S + r.sid], stf[F_RY * S + r.sid], stf[F_RZ * S + r.sid]);
-                r.rayFinite = finite3(r.trD);
-                pop = r.sp != 0u; top = CRT_TOP();
-                next = pop ? top : kRefDone; r.sp -= pop ? 1u : 0u;
-            }
-            if (COUNT && !more && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
-            r.cur = next;
-        }
-    };
-    // ---------------- A. swap out: streams whose walk is over park their hit and queue for shading ------------------------------
-    auto swap_out = [&](Res& r) {
-        const bool fin = r.res && r.cur == kRefDone;
-        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
-            bool toEnd = false;
-            if (fin) {
-                stf[F_T * S + r.sid] = r.h.t; stf[F_U * S + r.sid] = r.h.u; stf[F_V * S + r.sid] = r.h.v;
-                st[F_TRI * S + r.sid] = (uint32_t)r.h.triIdx;
-                const uint32_t meta = st[F_META * S + r.sid];
-                st[F_META * S + r.sid] = (meta & kMetaLowMask) | ((uint32_t)(r.h.objIdx + 1) << kMetaObjShift);
-                const uint32_t depth = (meta >> kMetaDepthShift) & 7u;
-                toEnd = r.h.objIdx == -1 || r.h.objIdx == 0 || (int)depth >= sc.depthLimit;
-                r.res = false;
-            }
-            const uint64_t mE = __builtin_amdgcn_ballot_w64(fin && toEnd), mB = __builtin_amdgcn_ballot_w64(fin && !toEnd);
-            if (fin && toEnd) qEnd[(endT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mE >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mE, 0u))) & kQueueMask] = (uint8_t)r.sid;
-            if (fin && !toEnd) qBnc[(bncT + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u))) & kQueueMask] = (uint8_t)r.sid;
-            endT += (uint32_t)__popcll(mE); bncT += (uint32_t)__popcll(mB);
-        }
-    };
-    // ---------------- C. swap in: free lanes take the next READY streams; E. the record loads of the set (consumed by its next walk) ----
-    auto swap_in_and_load = [&](Res& r) {
-        const uint32_t nRdy = rdyT - rdyH;
-        const uint64_t mFree = ~__builtin_amdgcn_ballot_w64(r.res);
-        if (nRdy != 0u && mFree != 0ull) {
-            const uint32_t myRank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mFree >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mFree, 0u));
-            if (!r.res && myRank < nRdy) {
-                r.sid = qRdy[(rdyH + myRank) & kQueueMask];
-                r.tO = mk3(stf[F_OX * S + r.sid], stf[F_OY * S + r.sid], stf[F_OZ * S + r.sid]);
-                r.tD = mk3(stf[F_DX * S + r.sid], stf[F_DY * S + r.sid], stf[F_DZ * S + r.sid]);
-                r.trD = mk3(stf[F_RX * S + r.sid], stf[F_RY * S + r.sid], stf[F_RZ * S + r.sid]);
-                r.h.t = stf[F_T * S + r.sid]; r.h.objIdx = (int)(st[F_META * S + r.sid] >> kMetaObjShift) - 1; r.h.u = 0; r.h.v = 0; r.h.triIdx = -1;
-                r.cur = st[F_CUR * S + r.sid];
-                const uint32_t pend = st[F_PEND * S + r.sid];
-                r.stk[0] = (uint16_t)pend; r.sp = pend ? 1u : 0u;                  // a dead store unless the far root child was hit
-                r.rayFinite = finite3(r.trD);
-                r.res = true;
-            }
-            const uint32_t nFree = (uint32_t)__popcll(mFree);
-            rdyH += nRdy < nFree ? nRdy : nFree;
-        }
-        const bool want = r.res && r.cur != kRefDone;
-        // record offset of a 16-bit reference: index * record size + section base (layout.h)
-        const uint32_t idx = r.cur & kRef16IndexMask;
-        uint32_t oa = (r.cur & kRef16Interior) ? idx * 64u : sc.leafOff - 48u + idx * 48u;     // NodePair | LeafTri
-        if (KIND == 1 && (r.cur & kRef16TlasBit) != 0u)
-            oa = (r.cur & kRef16Interior) ? sc.instOff + idx * 128u : sc.tlasPairOff + idx * 64u;   // TLAS leaf: Instance {invT rows, ids} | TLAS interior: its child pair
-        uint32_t ob = oa + 32u;
-        if (!want) { oa = 0u; ob = 32u; }
-        if (__builtin_amdgcn_ballot_w64(want) != 0ull) { r.q0 = ldg(geom, oa); r.q1 = ldg(geom, oa + 16u); r.q2 = ldg(geom, ob); r.q3 = ldg(geom, ob + 16u); }
-    };
-
     for (;;) {
         CRT_PSTAMP(p0);
-        uint32_t nRes = 0;
-#pragma unroll
-        for (int k = 0; k < SETS; k++) {
-            walk(R[k]);
+        if (mRes != 0ull) {
+            // ---------------- D. walk: the phases of the resident streams (TLAS leaf / NODE / TRI), on the records loaded by the previous trip ----------------
+            // what each resident lane is at, from its 16-bit reference: 10 = BVH interior, 00 = leaf triangle (never 0 here), 01 = TLAS interior, 11 = TLAS leaf
+            uint64_t mNode, mTlas = 0ull;
+            if (KIND == 0) mNode = mRes & __builtin_amdgcn_ballot_w64(cur > 0x7fffu);
+            else { mTlas = mRes & __builtin_amdgcn_ballot_w64(cur >= kRef16TlasLeaf); mNode = mRes & __builtin_amdgcn_ballot_w64(cur - kRef16TlasBit < 0x8000u); }
+            const uint64_t mTri = mRes & ~(mNode | mTlas);
+            // The record loads issued at the end of the previous trip are first needed here.  Naming all four tuples in one
+            // empty asm keeps the register allocator from splitting a loaded tuple across the back-edge.
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+            CRT_DENS(22, __popcll(mRes));
+            if (mNode) { CRT_DENS(1, 1); CRT_DENS(2, __popcll(mNode)); }
+            if (mTri) { CRT_DENS(3, 1); CRT_DENS(4, __popcll(mTri)); }
+            if (KIND == 1 && mTlas) { CRT_DENS(23, 1); CRT_DENS(24, __popcll(mTlas)); }
+            uint64_t mBack = 0ull;                                                 // lanes that popped the return marker: BLAS finished, back to the TLAS level
+            if (KIND == 1 && mTlas != 0ull) {
+                if (lane_in(mTlas)) {
+                    // ---------------- TLAS leaf (infra/tlas_bvh.cpp:91-95) -> enter the BLAS (BLASBVH::Intersect, blas_bvh.cpp:376-381) ----------
+                    if (COUNT) { cn.tlas++; cn.visits++; }
+                    const f3 O = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
+                    const f3 D = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
+                    to_object_space(q0, q1, q2, O, D, tO, tD, trD);
+                    spB += 128u; stk_put(spB, kRef16Return);
+                    const uint32_t next = asu(q3.y);                                 // Instance::rootRef16
+                    if (COUNT && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
+                    cur = next;
+                }
+                mFinite = (mFinite & ~mTlas) | (mTlas & __builtin_amdgcn_ballot_w64(finite3(trD)));
+            }
+            if (mNode != 0ull) {
+                // ---------------- NODE phase (infra/bvh.cpp:244-257) ------------------------------------------------------------------------
+                const bool allFinite = (mNode & ~mFinite) == 0ull;
+                if (lane_in(mNode)) {
+                    if (COUNT) { if (KIND == 1 && (cur & kRef16TlasBit) != 0u) cn.tlas++; else cn.interior++; }
+                    const uint32_t top = stk_top(spB);                               // speculative: lands during the slab arithmetic (the dummy entry when the stack is empty)
+                    float d1, d2;
+                    if (__builtin_expect(allFinite, 1)) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
+                    else { d1 = box_exact(q0, q1, tO, trD, h.t); d2 = box_exact(q2, q3, tO, trD, h.t); }
+                    const bool sw = d1 > d2;                                         // near child first (strict >: ties keep child 1)
+                    const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
+                    const uint32_t rn = sw ? asu(q3.w) : asu(q1.w), rf = sw ? asu(q1.w) : asu(q3.w);   // the children's ref16
+                    stk_put(spB + 128u, rf);                                         // dead store unless `push`
+                    const bool hitN = dn != 1e30f, push = hitN && df != 1e30f;
+                    const bool pop = !hitN && spB != laneB;
+                    cur = hitN ? rn : (pop ? top : kRefDone);
+                    spB = spB + (push ? 128u : 0u) - (pop ? 128u : 0u);
+                    if (COUNT && (cur & kRef16TagMask) == 0u && cur != kRefDone) cn.leaf++;
+                }
+            }
+            if (mTri != 0ull) {
+                if (lane_in(mTri)) {
+                    // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:203-222, 232-243) -------------------------------
+                    if (COUNT) cn.tri++;
+                    const uint32_t top = stk_top(spB);
+                    hit_tri(q0, q1, q2, tO, tD, h);
+                    const bool more = asu(q2.w) > 1u;                                // the leaf's next LeafTri is the next index
+                    const bool pop = !more && spB != laneB;
+                    const uint32_t next = more ? cur + 1u : (pop ? top : kRefDone);
+                    spB -= pop ? 128u : 0u;
+                    if (COUNT && !more && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
+                    cur = next;
+                }
+            }
+            if (KIND == 1) {
+                // a popped return marker: the BLAS is finished — back to the world-space ray, pop the TLAS entry below (rare: once per BLAS visit)
+                mBack = (mNode | mTri) & __builtin_amdgcn_ballot_w64(cur == kRef16Return);
+                if (mBack != 0ull) {
+                    if (lane_in(mBack)) {
+                        world_ray();
+                        const bool pop = spB != laneB;
+                        const uint32_t top = stk_top(spB);
+                        cur = pop ? top : kRefDone; spB -= pop ? 128u : 0u;
+                        if (COUNT && (cur & kRef16TagMask) == 0u && cur != kRefDone) cn.leaf++;
+                    }
+                    mFinite = (mFinite & ~mBack) | (mBack & __builtin_amdgcn_ballot_w64(finite3(trD)));
+                }
+            }
             asm volatile("" ::: "memory");          // (the sections exchange stream state through LDS across lanes: nothing is carried over in registers)
-            swap_out(R[k]);
+            // ---------------- A. swap out: streams whose walk is over park their hit and queue for shading ------------------------------
+            const uint64_t mFin = mRes & __builtin_amdgcn_ballot_w64(cur == kRefDone);
+            if (mFin != 0ull) {
+                CRT_DENS(5, 1); CRT_DENS(6, __popcll(mFin));
+                const uint32_t depth = (metaLo >> kMetaDepthShift) & 7u;
+                const uint64_t mStop = __builtin_amdgcn_ballot_w64((uint32_t)(h.objIdx + 1) <= 1u) | __builtin_amdgcn_ballot_w64((int)depth >= sc.depthLimit);   // miss, light, or depth limit
+                const uint64_t mE = mFin & mStop, mB = mFin & ~mStop;
+                if (lane_in(mFin)) {
+                    stf[F_T * S + sid] = h.t; stf[F_U * S + sid] = h.u; stf[F_V * S + sid] = h.v;
+                    st[F_TRI * S + sid] = (uint32_t)h.triIdx;
+                    st[F_META * S + sid] = metaLo | ((uint32_t)(h.objIdx + 1) << kMetaObjShift);
+                }
+                if (lane_in(mE)) qEnd[(endT + rank_in(mE)) & kQueueMask] = (uint8_t)sid;
+                if (lane_in(mB)) qBnc[(bncT + rank_in(mB)) & kQueueMask] = (uint8_t)sid;
+                endT += (uint32_t)__popcll(mE); bncT += (uint32_t)__popcll(mB);
+                mRes &= ~mFin;
+            }
             asm volatile("" ::: "memory");
-            if (k + 1 < SETS) { swap_in_and_load(R[k]); asm volatile("" ::: "memory"); }     // (the last set swaps in after the exit test)
-            nRes += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(R[k].res));
         }
         {
             const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH;
-            if (nEnd + nBnc + nRdy + nRes == 0u) break;
+            if (nEnd + nBnc + nRdy == 0u && mRes == 0ull) break;
             if (COUNT) trips++;
+            CRT_DENS(0, 1);
         }
-        swap_in_and_load(R[SETS - 1]);
+        // ---------------- C. swap in: free lanes take the next READY streams; E. the record loads (consumed by the next trip's walk) ----
+        {
+            const uint32_t nRdy = rdyT - rdyH;
+            const uint64_t mFree = ~mRes;
+            if (nRdy != 0u && mFree != 0ull) {
+                const uint32_t myRank = rank_in(mFree);
+                const uint64_t mTake = mFree & __builtin_amdgcn_ballot_w64(myRank < nRdy);      // the first min(nRdy, free) free lanes
+                CRT_DENS(7, 1); CRT_DENS(8, __popcll(mTake));
+                if (lane_in(mTake)) {
+                    sid = qRdy[(rdyH + myRank) & kQueueMask];
+                    tO = mk3(stf[F_OX * S + sid], stf[F_OY * S + sid], stf[F_OZ * S + sid]);
+                    tD = mk3(stf[F_DX * S + sid], stf[F_DY * S + sid], stf[F_DZ * S + sid]);
+                    trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
+                    const uint32_t meta = st[F_META * S + sid];
+                    h.t = stf[F_T * S + sid]; h.objIdx = (int)(meta >> kMetaObjShift) - 1; h.u = 0; h.v = 0; h.triIdx = -1;
+                    metaLo = meta & kMetaLowMask;
+                    cur = st[F_CUR * S + sid];
+                    const uint32_t pend = st[F_PEND * S + sid];
+                    stk_put(laneB + 128u, pend);                                     // a dead store unless the far root child was hit
+                    spB = laneB + (pend ? 128u : 0u);
+                }
+                mFinite = (mFinite & ~mTake) | (mTake & __builtin_amdgcn_ballot_w64(finite3(trD)));
+                mRes |= mTake;
+                rdyH += (uint32_t)__popcll(mTake);
+            }
+            if (mRes != 0ull) {
+                CRT_DENS(21, 1);
+                // record offset of a 16-bit reference: index * record size + section base (layout.h); lanes without a stream re-read record 0
+                const uint32_t idx = cur & kRef16IndexMask;
+                uint32_t oa = (cur & kRef16Interior) ? idx * 64u : sc.leafOff - 48u + idx * 48u;     // NodePair | LeafTri
+                if (KIND == 1 && (cur & kRef16TlasBit) != 0u)
+                    oa = (cur & kRef16Interior) ? sc.instOff + idx * 128u : sc.tlasPairOff + idx * 64u;   // TLAS leaf: Instance {invT rows, ids} | TLAS interior: its child pair
+                if (!lane_in(mRes)) oa = 0u;
+                q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, oa + 32u); q3 = ldg(geom, oa + 48u);
+            }
+        }
         CRT_PSTAMP(p2);
         asm volatile("" ::: "memory");
         {
             // ---------------- B. shading passes (their latency-free arithmetic also covers the record loads just issued) --------------------
-            uint32_t nResNow = 0;
-#pragma unroll
-            for (int k = 0; k < SETS; k++) nResNow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(R[k].res));
-            const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH, nRes = nResNow;
+            const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH, nRes = (uint32_t)__popcll(mRes);
             // a shading pass waits for a full wavefront of streams unless the walking side runs dry
             const bool starving = nRes + nRdy < (uint32_t)CRT_POOL_STARVE;
             const bool runEnd = nEnd >= (uint32_t)CRT_POOL_SHADE_MIN || (starving && nEnd > 0u && nEnd >= nBnc);
@@ -352,6 +372,7 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
                 const int depth = (int)((meta >> kMetaDepthShift) & 7u);
                 uint32_t item = meta & kMetaItemMask;
                 const bool ended = act && !first, miss = ended && obj == -1;
+                CRT_DENS(9, 1); CRT_DENS(10, n); CRT_DENS_MASK(11, miss); CRT_DENS_MASK(13, act && first); CRT_DENS_MASK(25, ended && depth > 0); CRT_DENS_MASK(26, ended && depth > 1); CRT_DENS_MASK(27, ended && depth > 2);
                 if (ended && obj >= 2) cn.meshhits++;
                 // the path's throughput factors: fetched now (device-scope loads: they were written by this wave's BOUNCE passes, possibly from
                 // another lane), needed after the sky lookup; most paths end at depth 0..2 and a level is fetched only by the lanes that deep
@@ -397,6 +418,7 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
                     v = P - camPos;
                     cn.primary++;
                 }
+                CRT_DENS_MASK(12, gen);
                 new_ray(gen, s, v, true, camPos, seed, item);                      // depth 0, outside, not fresh
                 if (ended) {
                     // the finished path's radiance: sky colour / light (24,24,22) / 0 at the depth limit (renderer.cpp:54-55, 69; GetLightColor file_scene.cpp:164-167), times the
@@ -428,6 +450,7 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
                     seed = st[F_SEED * S + s]; meta = st[F_META * S + s]; obj = (int)(meta >> kMetaObjShift) - 1;
                 }
                 const bool mesh = act && obj >= 2;
+                CRT_DENS(14, 1); CRT_DENS(15, n); CRT_DENS_MASK(16, mesh);
                 rec4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;                 // the hit triangle's ShadeTri
                 if (mesh) { const uint32_t so = sc.shadeOff + tri * 64u; s0 = ldg(geom, so); s1 = ldg(geom, so + 16u); s2 = ldg(geom, so + 32u); s3 = ldg(geom, so + 48u); cn.meshhits++; }
                 const bool inside = (meta & kMetaInside) != 0u;
@@ -528,7 +551,9 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
 #ifdef CRT_POOL_STAMPS
     if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&counters->v[2 + i], pst[i]);
 #endif
-#undef CRT_TOP
+#ifdef CRT_POOL_DENS
+    if (lane == 0) for (int i = 0; i < 32; i++) if (dens[i]) atomicAdd(&g_poolDens[i], (unsigned long long)dens[i]);
+#endif
 
 #ifdef CRT_POOL_TIMELINE
     if (lane == 0 && g_poolTimeline) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_poolTimeline[3 * (size_t)blockIdx.x] = tl0; g_poolTimeline[3 * (size_t)blockIdx.x + 1] = wall_clock64(); g_poolTimeline[3 * (size_t)blockIdx.x + 2] = hw; }
@@ -558,14 +583,23 @@ __global__ __launch_bounds__(64, (SETS == 2 ? 3 : CRT_POOL_MIN_WAVES)) void rend
 #define CRT_POOL_STREAMS 128
 #endif
 extern "C" uint32_t crt_pool_streams(uint32_t frames) { return frames > 64u ? (uint32_t)CRT_POOL_STREAMS : 64u; }
-#ifndef CRT_POOL_SETS
-#define CRT_POOL_SETS 1            // resident sets per lane in launches of more than 64 frames (2 = dual mode)
+#ifndef CRT_POOL_EXTRA_LDS
+#define CRT_POOL_EXTRA_LDS 0       // occupancy experiments only: unused LDS bytes per wavefront
 #endif
-extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackDepth, uint32_t streams, uint32_t sets) { return sets * stackDepth * 64u * 2u + crt::F_COUNT * streams * 4u + 3u * 128u; }
+// LDS of one wavefront: traversal stacks ((stackDepth + 1 dummy) two-byte entries per lane) + parked stream state + the three one-byte ring queues
+extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackDepth, uint32_t streams) { return (stackDepth + 1u) * 64u * 2u + crt::F_COUNT * streams * 4u + 3u * 128u + (uint32_t)CRT_POOL_EXTRA_LDS; }
 // bytes of throughput-factor scratch a launch of `windows` 64-frame windows needs behind its sample slab (15 floats per stream; a wave's
 // group of streams may reach past the last window, hence 128 stream slots per window)
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t tileCount) { return (size_t)tileCount * 128u * 15u * 4u; }
 
+#ifdef CRT_POOL_DENS
+extern "C" int crt_debug_pool_density(unsigned long long* out, int reset)      // after a sync: the 32 section counters summed over every pool wave since the last reset
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(crt::g_poolDens), 256) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(crt::g_poolDens), z, 256) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #ifdef CRT_POOL_TIMELINE
 static unsigned long long* g_timelineHost = nullptr; static size_t g_timelineCount = 0;
 extern "C" size_t crt_debug_pool_timeline(unsigned long long* out, size_t cap)        // after a sync: 3 words per wavefront of the last pool launch
@@ -591,10 +625,9 @@ extern "C" hipError_t crt_launch_render_pool(const crt::Scene* sc, void* slab, v
       if (cap < (size_t)grid.x) { if (buf) (void)hipFree(buf); (void)hipMalloc((void**)&buf, (size_t)grid.x * 24); cap = grid.x; (void)hipMemcpyToSymbol(HIP_SYMBOL(crt::g_poolTimeline), &buf, sizeof(buf)); }
       (void)hipMemsetAsync(buf, 0, (size_t)grid.x * 24, stream); g_timelineHost = buf; g_timelineCount = grid.x; }
 #endif
-    const uint32_t sets = S == 64u ? 1u : (uint32_t)CRT_POOL_SETS;
-    const uint32_t ldsBytes = crt_pool_lds_bytes(sc->stackDepth, S, sets);
-#define CRT_LAUNCH(K, C, SS, NS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS, NS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups, rankFirst, tileCost, launchClk)
-#define CRT_LAUNCH_S(K, C) do { if (S == 64u) CRT_LAUNCH(K, C, 64, 1); else CRT_LAUNCH(K, C, CRT_POOL_STREAMS, CRT_POOL_SETS); } while (0)
+    const uint32_t ldsBytes = crt_pool_lds_bytes(sc->stackDepth, S);
+#define CRT_LAUNCH(K, C, SS) hipLaunchKernelGGL((crt::render_pool_kernel<K, C, SS>), grid, block, ldsBytes, stream, *sc, (float4*)slab, (float*)facScratch, counters, tileClocks, tileOrder, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, groups, rankFirst, tileCost, launchClk)
+#define CRT_LAUNCH_S(K, C) do { if (S == 64u) CRT_LAUNCH(K, C, 64); else CRT_LAUNCH(K, C, CRT_POOL_STREAMS); } while (0)
     if (sc->kind == 0) { if (collectStats) CRT_LAUNCH_S(0, true); else CRT_LAUNCH_S(0, false); }
     else { if (collectStats) CRT_LAUNCH_S(1, true); else CRT_LAUNCH_S(1, false); }
 #undef CRT_LAUNCH_S

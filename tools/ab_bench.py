@@ -8,6 +8,35 @@ VDIR = os.path.join(REPO, "build", "variants")
 PKG = os.path.join(REPO, "cpu-ray-tracer_amd")
 SRC = ["csrc/device/kernels.hip", "csrc/device/render_pool.hip", "csrc/device/alt_accel.hip", "csrc/abi.cpp", "csrc/host/accel.cpp", "csrc/host/accel_alt.cpp", "csrc/host/loaders.cpp", "csrc/host/scene.cpp", "csrc/host/host_abi.cpp"]
 
+def fastbuild(specs):
+    """variants that only differ in render_pool.hip: everything else is compiled once into build/obj/ and re-linked (seconds per variant)"""
+    odir = os.path.join(REPO, "build", "obj"); os.makedirs(odir, exist_ok=True); os.makedirs(VDIR, exist_ok=True)
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Xarch_device", "-fno-slp-vectorize"]
+    objs = []
+    for src in SRC:
+        if src.endswith("render_pool.hip"): continue
+        o = os.path.join(odir, os.path.basename(src) + ".o"); objs.append(o)
+        deps = [os.path.join(PKG, src)] + [os.path.join(PKG, "csrc/device", h) for h in ("dev_common.h", "layout.h")] + [os.path.join(REPO, "include", h) for h in ("crt_abi.h", "crt_host.h")]
+        if not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in deps):
+            subprocess.check_call(base + ["-c", "-o", o, src], cwd=PKG)
+    procs = []
+    for spec in specs:
+        name, _, flags = spec.partition("=")
+        po = os.path.join(odir, "pool_%s.o" % name)
+        out = os.path.join(VDIR, "libcrt_%s.so" % name)
+        src = "csrc/device/render_pool.hip"
+        fl = flags.split()
+        if fl and fl[0].startswith("@"):      # NAME=@/path/to/another/render_pool.hip [flags]: an older version of the kernel as a variant
+            src = fl[0][1:]; fl = fl[1:] + ["-I" + os.path.join(PKG, "csrc/device")]
+        cmd = " ".join(base + fl + ["-c", "-o", po, src]) + " && " + " ".join(base + ["-shared", "-o", out, po] + objs + ["-lz"])
+        procs.append((name, subprocess.Popen(cmd, shell=True, cwd=PKG)))
+        if len(procs) >= 6:
+            for n, pr in procs:
+                if pr.wait() != 0: sys.exit("variant %s failed to build" % n)
+            procs = []
+    for n, pr in procs:
+        if pr.wait() != 0: sys.exit("variant %s failed to build" % n)
+
 def build(specs):
     os.makedirs(VDIR, exist_ok=True)
     for spec in specs:
@@ -52,4 +81,5 @@ print("single-launch %%.3f ms | 56 calls pipelined %%.3f ms/step | one 64-window
 
 if __name__ == "__main__":
     if sys.argv[1] == "build": build(sys.argv[2:])
+    elif sys.argv[1] == "fastbuild": fastbuild(sys.argv[2:])
     else: run(sys.argv[2:])

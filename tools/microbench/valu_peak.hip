@@ -5,6 +5,9 @@
 //   mix     v_mul_f32 / v_add_f32 / v_cndmask / v_max3 mix on 4 chains (the render kernel's flavour: no FMA contraction)
 //   pk      v_pk_mul_f32 on 4 chains
 //   rcp     v_rcp_f32 (quarter-rate transcendental unit)
+//   int     xorshift32 steps (v_lshlrev / v_lshrrev / v_xor) on 2 chains — the RNG of the render kernels
+//   cmp     v_cmp_lt_f32 vcc + v_cndmask pairs on 4 chains (box_exact / select chains)
+//   salu    the mix block with one s_add_u32 after every VALU instruction (scalar work interleaved, as in the render loops)
 // for 1, 2, 4, 5 and 8 waves per SIMD.  Output: G wave-instructions/s over the whole chip and cycles per instruction per SIMD at the
 // clock implied by the fastest case.   Build: hipcc --offload-arch=gfx950 -O3 -o valu_peak valu_peak.hip ;  run: ./valu_peak
 #include <hip/hip_runtime.h>
@@ -33,6 +36,12 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float b, float c)
             a0 = x0.x; p0 = x0.y; a1 = x1.x; p1 = x1.y; a2 = x2.x; a3 = x3.x;
         }
         if (MODE == 4) asm volatile(R16("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        if (MODE == 5) asm volatile(R16("v_lshlrev_b32 %2, 13, %0\n v_xor_b32 %0, %0, %2\n v_lshrrev_b32 %3, 17, %1\n v_xor_b32 %1, %1, %3\n")
+                                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        if (MODE == 6) asm volatile(R16("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %0, vcc\n v_cmp_lt_f32 vcc, %1, %3\n v_cndmask_b32 %3, %3, %1, vcc\n")
+                                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");
+        if (MODE == 7) asm volatile(R16("v_mul_f32 %0, %0, %4\n s_add_u32 s20, s20, 1\n v_add_f32 %1, %1, %5\n s_add_u32 s21, s21, 1\n v_cndmask_b32 %2, %2, %0, vcc\n s_add_u32 s22, s22, 1\n v_max3_f32 %3, %3, %1, %2\n s_add_u32 s23, s23, 1\n")
+                                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22", "s23", "scc");
     }
     out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + p0 + p1;
 }
@@ -56,12 +65,13 @@ int main()
     const int simds = p.multiProcessorCount * 4;
     printf("%s: %d CUs, %d SIMDs, clock %d MHz\n", p.name, p.multiProcessorCount, simds, p.clockRate / 1000);
     float* d; hipMalloc(&d, (size_t)simds * 8 * 64 * 4);
-    const char* names[5] = {"dep", "ind4", "mix", "pk", "rcp"};
+    const char* names[8] = {"dep", "ind4", "mix", "pk", "rcp", "int", "cmp", "salu(VALU only counted)"};
     const int iters = 20000;
     for (int w : {1, 2, 4, 5, 8}) {
-        double r[5] = {run<0>(d, w, simds, iters), run<1>(d, w, simds, iters), run<2>(d, w, simds, iters), run<3>(d, w, simds, iters), run<4>(d, w, simds, iters / 4)};
+        double r[8] = {run<0>(d, w, simds, iters), run<1>(d, w, simds, iters), run<2>(d, w, simds, iters), run<3>(d, w, simds, iters), run<4>(d, w, simds, iters / 4),
+                       run<5>(d, w, simds, iters), run<6>(d, w, simds, iters), run<7>(d, w, simds, iters)};
         printf("%d wave(s)/SIMD:", w);
-        for (int m = 0; m < 5; m++) printf("  %s %.0f G/s (%.2f cyc/instr/SIMD @2.4GHz)", names[m], r[m] / 1e9, 2.4e9 * simds / r[m]);
+        for (int m = 0; m < 8; m++) printf("  %s %.0f G/s (%.2f cyc/instr/SIMD @2.4GHz)", names[m], r[m] / 1e9, 2.4e9 * simds / r[m]);
         printf("\n");
     }
     return 0;
