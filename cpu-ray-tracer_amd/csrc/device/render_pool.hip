@@ -53,11 +53,15 @@ constexpr uint32_t kQueueMask = 127u;                            // queues are r
 #endif
 
 #ifdef CRT_POOL_STAMPS
-// diagnostic build only (-DCRT_POOL_STAMPS): shader-clock time of the sections of the loop, summed over all waves into the (otherwise unused) counter
-// slots 2..6 of a non-counting launch: [2] walk (incl. the wait for the records) + swap out / in + record loads, [3] unused, [4] END passes, [5] BOUNCE passes, [6] trips
+// diagnostic build only (-DCRT_POOL_STAMPS, tools/pool_stamps.py): shader-clock time of the sections of the loop, summed over all waves:
+// [0] walk phases + swap out (incl. the wait for the records), [1] swap in + record loads + pass decision, [2] END pass up to its new_ray, [3] END's new_ray, [4] END tail (unwind, store),
+// [5] BOUNCE up to the material draw, [6] material draw + rejection loop, [7] normalise + factor store, [8] BOUNCE's new_ray, [9] trips, [10] END passes, [11] BOUNCE passes
+__device__ unsigned long long g_poolStamps[16];
 #define CRT_PSTAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define CRT_PACC(i, a, b) (pst[i] += (b) - (a))
 #else
 #define CRT_PSTAMP(var)
+#define CRT_PACC(i, a, b)
 #endif
 #ifdef CRT_POOL_DENS
 // diagnostic build only (-DCRT_POOL_DENS, tools/pool_density.py): how often every section of the loop runs and with how many lanes, summed over all waves
@@ -76,6 +80,11 @@ __device__ unsigned long long* g_poolTimeline = nullptr;
 // per-lane predicate is `lane_in(mask)` = the mask used directly as the execution / select mask (amdgcn inverse ballot): no v_cndmask + v_cmp round trip per
 // ballot, and `resident` never has to be re-derived from lane state.
 __device__ __forceinline__ bool lane_in(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ uint64_t finite3_mask(f3 v)          // lanes whose three components are all finite: three compares straight into scalar masks
+{
+    const uint32_t m = 0x7f800000u;
+    return __builtin_amdgcn_ballot_w64((asu(v.x) & m) != m) & __builtin_amdgcn_ballot_w64((asu(v.y) & m) != m) & __builtin_amdgcn_ballot_w64((asu(v.z) & m) != m);
+}
 __device__ __forceinline__ uint32_t rank_in(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }   // set bits below this lane
 
 template <int KIND, bool COUNT, int S>
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
     };
 
 #ifdef CRT_POOL_STAMPS
-    unsigned long long pst[5] = {0, 0, 0, 0, 0};
+    unsigned long long pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (;;) {
         CRT_PSTAMP(p0);
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                     if (COUNT && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
                     cur = next;
                 }
-                mFinite = (mFinite & ~mTlas) | (mTlas & __builtin_amdgcn_ballot_w64(finite3(trD)));
+                mFinite = (mFinite & ~mTlas) | (mTlas & finite3_mask(trD));
             }
             if (mNode != 0ull) {
                 // ---------------- NODE phase (infra/bvh.cpp:244-257) ------------------------------------------------------------------------
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                         cur = pop ? top : kRefDone; spB -= pop ? 128u : 0u;
                         if (COUNT && (cur & kRef16TagMask) == 0u && cur != kRefDone) cn.leaf++;
                     }
-                    mFinite = (mFinite & ~mBack) | (mBack & __builtin_amdgcn_ballot_w64(finite3(trD)));
+                    mFinite = (mFinite & ~mBack) | (mBack & finite3_mask(trD));
                 }
             }
             asm volatile("" ::: "memory");          // (the sections exchange stream state through LDS across lanes: nothing is carried over in registers)
@@ -308,17 +317,17 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
             }
             asm volatile("" ::: "memory");
         }
-        {
-            const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH;
-            if (nEnd + nBnc + nRdy == 0u && mRes == 0ull) break;
-            if (COUNT) trips++;
-            CRT_DENS(0, 1);
+        CRT_PSTAMP(p1); CRT_PACC(0, p0, p1);
+        if (__builtin_expect(mRes == 0ull, 0)) {
+            if ((endT - endH) + (bncT - bncH) + (rdyT - rdyH) == 0u) break;       // every stream has rendered its 256 pixels
         }
+        if (COUNT) trips++;
+        CRT_DENS(0, 1);
         // ---------------- C. swap in: free lanes take the next READY streams; E. the record loads (consumed by the next trip's walk) ----
         {
             const uint32_t nRdy = rdyT - rdyH;
             const uint64_t mFree = ~mRes;
-            if (nRdy != 0u && mFree != 0ull) {
+            if (nRdy != 0u) if (mFree != 0ull) {
                 const uint32_t myRank = rank_in(mFree);
                 const uint64_t mTake = mFree & __builtin_amdgcn_ballot_w64(myRank < nRdy);      // the first min(nRdy, free) free lanes
                 CRT_DENS(7, 1); CRT_DENS(8, __popcll(mTake));
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                     stk_put(laneB + 128u, pend);                                     // a dead store unless the far root child was hit
                     spB = laneB + (pend ? 128u : 0u);
                 }
-                mFinite = (mFinite & ~mTake) | (mTake & __builtin_amdgcn_ballot_w64(finite3(trD)));
+                mFinite = (mFinite & ~mTake) | (mTake & finite3_mask(trD));
                 mRes |= mTake;
                 rdyH += (uint32_t)__popcll(mTake);
             }
@@ -343,23 +352,27 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                 CRT_DENS(21, 1);
                 // record offset of a 16-bit reference: index * record size + section base (layout.h); lanes without a stream re-read record 0
                 const uint32_t idx = cur & kRef16IndexMask;
-                uint32_t oa = (cur & kRef16Interior) ? idx * 64u : sc.leafOff - 48u + idx * 48u;     // NodePair | LeafTri
+                const bool inter = (cur & kRef16Interior) != 0u;
+                uint32_t oa = idx * (inter ? 64u : 48u) + (inter ? 0u : sc.leafOff - 48u);             // NodePair | LeafTri (one multiply-add on selected operands: no divergent arms)
                 if (KIND == 1 && (cur & kRef16TlasBit) != 0u)
                     oa = (cur & kRef16Interior) ? sc.instOff + idx * 128u : sc.tlasPairOff + idx * 64u;   // TLAS leaf: Instance {invT rows, ids} | TLAS interior: its child pair
                 if (!lane_in(mRes)) oa = 0u;
                 q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, oa + 32u); q3 = ldg(geom, oa + 48u);
             }
         }
-        CRT_PSTAMP(p2);
         asm volatile("" ::: "memory");
         {
             // ---------------- B. shading passes (their latency-free arithmetic also covers the record loads just issued) --------------------
             const uint32_t nEnd = endT - endH, nBnc = bncT - bncH, nRdy = rdyT - rdyH, nRes = (uint32_t)__popcll(mRes);
             // a shading pass waits for a full wavefront of streams unless the walking side runs dry
             const bool starving = nRes + nRdy < (uint32_t)CRT_POOL_STARVE;
-            const bool runEnd = nEnd >= (uint32_t)CRT_POOL_SHADE_MIN || (starving && nEnd > 0u && nEnd >= nBnc);
-            const bool runBnc = nBnc >= (uint32_t)CRT_POOL_SHADE_MIN || (starving && nBnc > nEnd);
+            bool runEnd = false, runBnc = false;
+            if ((nEnd | nBnc) >= (uint32_t)CRT_POOL_SHADE_MIN || starving) {      // (64 is a power of two: either count >= 64 <=> the OR is; rings hold <= 128)
+                runEnd = nEnd >= (uint32_t)CRT_POOL_SHADE_MIN || (starving && nEnd > 0u && nEnd >= nBnc);
+                runBnc = nBnc >= (uint32_t)CRT_POOL_SHADE_MIN || (starving && nBnc > nEnd);
+            }
 
+            CRT_PSTAMP(p2b); CRT_PACC(1, p1, p2b);
             if (runEnd) {
                 // ---------------- B1. END pass: the path of each stream ended (renderer.cpp:54-55, 69) or has not begun ----------------
                 const uint32_t n = nEnd < 64u ? nEnd : 64u;
@@ -419,7 +432,9 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                     cn.primary++;
                 }
                 CRT_DENS_MASK(12, gen);
+                CRT_PSTAMP(e1); CRT_PACC(2, p2b, e1);
                 new_ray(gen, s, v, true, camPos, seed, item);                      // depth 0, outside, not fresh
+                CRT_PSTAMP(e2); CRT_PACC(3, e1, e2);
                 if (ended) {
                     // the finished path's radiance: sky colour / light (24,24,22) / 0 at the depth limit (renderer.cpp:54-55, 69; GetLightColor file_scene.cpp:164-167), times the
                     // throughput factors in recursion order (innermost first: albedo*medium*Sample(...) multiplies on return)
@@ -429,11 +444,14 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                         if (depth > k) L = mk3(fk[3 * k], fk[3 * k + 1], fk[3 * k + 2]) * L;
                     slab[sampleAt] = make_float4(L.x, L.y, L.z, 0.0f);
                 }
+                // every load of this pass is named as consumed here, at its end, on every path: the registers they wrote are re-used by the next sections, and a load
+                // the compiler cannot prove finished would put a wait for ALL outstanding loads — the record loads in flight included — in front of that first re-use
+#ifdef CRT_POOL_STAMPS
+                { CRT_PSTAMP(e3); CRT_PACC(4, e2, e3); pst[10]++; }
+#endif
+                asm volatile("" :: "v"(fk[0]), "v"(fk[1]), "v"(fk[2]), "v"(fk[3]), "v"(fk[4]), "v"(fk[5]), "v"(fk[6]), "v"(fk[7]), "v"(fk[8]), "v"(fk[9]), "v"(fk[10]), "v"(fk[11]), "v"(fk[12]), "v"(fk[13]), "v"(fk[14]), "v"(skyTexel));
             }
             CRT_PSTAMP(p3);
-#ifdef CRT_POOL_STAMPS
-            pst[2] += p3 - p2;
-#endif
             asm volatile("" ::: "memory");
             if (runBnc) {
                 // ---------------- B2. BOUNCE pass: surface hit (floor or mesh) below the depth limit (renderer.cpp:56-99) ----------------
@@ -494,18 +512,20 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                         }
                     }
                     if (dot3(N, D) > 0) N = -N;
-                    f3 c = mk3(1.0f, 1.0f, 1.0f);
-                    if (tW > 0) c = tex_sample(sc, tOff, tW, tH, tu, tv);          // Material::GetAlbedo
+                    // Material::GetAlbedo: the texel fetch is issued here and consumed after the direction has been drawn (its latency hides behind the rejection loop)
+                    uint32_t texel = 0x00ffffffu;
+                    if (tW > 0) texel = sc.texels[tex_index(tOff, tW, tH, tu, tv)];
                     f3 medium = mk3(1, 1, 1);
                     if (inside) {
                         const f3 ab = absorb * -ht;
                         medium = mk3(crt_expf(ab.x), crt_expf(ab.y), crt_expf(ab.z));
                     }
+                    CRT_PSTAMP(b1); CRT_PACC(5, p3, b1);
                     const float r = rnd(seed);
-                    if (r < refl) {                                                // HandleMirror, renderer.cpp:20-25
+                    const bool mirror = r < refl, dielectric = !mirror && r < refl + refr;
+                    if (mirror) {                                                  // HandleMirror, renderer.cpp:20-25
                         v = D - 2.0f * N * dot3(N, D);
-                        pre = c * medium;
-                    } else if (r < refl + refr) {                                  // HandleDielectric, renderer.cpp:27-45
+                    } else if (dielectric) {                                       // HandleDielectric, renderer.cpp:27-45
                         v = D - 2.0f * N * dot3(N, D);
                         const float n1 = inside ? 1.2f : 1, n2 = inside ? 1 : 1.2f;
                         const float eta = n1 / n2, cosi = dot3(-D, N);
@@ -516,7 +536,6 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                             const f3 T = eta * D + ((eta * cosi - __builtin_sqrtf(__builtin_fabsf(cost2))) * N);
                             if (rnd(seed) > Fr) { v = T; newInside = !inside; }
                         }
-                        pre = c * medium;
                     } else {                                                       // diffuse, renderer.cpp:93-99; diffusereflection tmplmath.h:535-544
                         f3 Rr;
                         do {
@@ -527,9 +546,14 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                         } while (dot3(Rr, Rr) > 1);
                         if (dot3(Rr, N) < 0) Rr = Rr * -1.0f;
                         v = Rr; norm = true; diffuse = true;
+                    }
+                    // albedo (1,1,1 untextured: 0xffffff * (1/255) == 1 exactly) and the factor without the cosine term of the diffuse branch
+                    const f3 c = (tW > 0) ? tex_unpack(texel) : mk3(1.0f, 1.0f, 1.0f);
+                    if (diffuse) {
                         const f3 brdf = c * CRT_INVPI;
                         pre = medium * brdf * 2.0f * CRT_PI;                       // ... * dot(R, N) once R is normalised
-                    }
+                    } else pre = c * medium;
+                    CRT_PSTAMP(b2); CRT_PACC(6, b1, b2);
                     // normalize(R) of the diffuse branch; the bounce's throughput factor and the new origin use the normalised direction
                     const float inv = rcp_exact(__builtin_sqrtf(dot3(v, v)));
                     const f3 nv = norm ? v * inv : v;
@@ -540,16 +564,22 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                     __hip_atomic_store(fd + S, factor.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(fd + 2 * S, factor.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     O = I + nv * CRT_EPS;
+                    CRT_PSTAMP(b3); CRT_PACC(7, b2, b3);
                 }
+                CRT_PSTAMP(b4);
                 new_ray(act, s, v, false, O, seed, item | ((uint32_t)(depth + 1) << kMetaDepthShift) | (newInside ? kMetaInside : 0u));
+#ifdef CRT_POOL_STAMPS
+                { CRT_PSTAMP(b5); CRT_PACC(8, b4, b5); pst[11]++; }
+#endif
+                asm volatile("" :: "v"(s0), "v"(s1), "v"(s2), "v"(s3));            // (as at the end of the END pass)
             }
 #ifdef CRT_POOL_STAMPS
-            { CRT_PSTAMP(p4); pst[0] += p2 - p0; pst[3] += p4 - p3; pst[4]++; }
+            pst[9]++;
 #endif
         }
     }
 #ifdef CRT_POOL_STAMPS
-    if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&counters->v[2 + i], pst[i]);
+    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_poolStamps[i], pst[i]);
 #endif
 #ifdef CRT_POOL_DENS
     if (lane == 0) for (int i = 0; i < 32; i++) if (dens[i]) atomicAdd(&g_poolDens[i], (unsigned long long)dens[i]);
@@ -592,6 +622,14 @@ extern "C" uint32_t crt_pool_lds_bytes(uint32_t stackDepth, uint32_t streams) { 
 // group of streams may reach past the last window, hence 128 stream slots per window)
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t tileCount) { return (size_t)tileCount * 128u * 15u * 4u; }
 
+#ifdef CRT_POOL_STAMPS
+extern "C" int crt_debug_pool_stamps(unsigned long long* out, int reset)       // after a sync: the section clocks summed over every pool wave since the last reset
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(crt::g_poolStamps), 128) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(crt::g_poolStamps), z, 128) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #ifdef CRT_POOL_DENS
 extern "C" int crt_debug_pool_density(unsigned long long* out, int reset)      // after a sync: the 32 section counters summed over every pool wave since the last reset
 {
