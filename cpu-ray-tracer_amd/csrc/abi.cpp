@@ -21,6 +21,8 @@ extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
 extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t*, unsigned long long*, hipStream_t);
 extern "C" uint32_t crt_pool_streams(uint32_t frames);
+extern "C" uint32_t crt_narrow_max_lanes(void);
+extern "C" hipError_t crt_launch_render_narrow(const crt::Scene*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_whitted(const crt::Scene*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
@@ -63,6 +65,7 @@ struct crt_ctx {
     // the GPU; the ordered accumulate kernels run on the main stream behind events.  Their sample slabs are regions of ONE pool
     // handed out as a ring: launch order = accumulate order = release order, so the oldest region is always the next to free.
     std::vector<hipStream_t> streams; uint64_t launchSeq = 0;
+    hipStream_t narrowStream = nullptr;                          // highest priority: render_narrow_kernel's workgroups (32+ KB of LDS each) must not queue behind the wide kernel's wavefronts
     struct Region { size_t off, bytes; hipEvent_t freed; };      // freed: recorded on the main stream behind the region's accumulate
     std::deque<Region> inflight;
     char* pool = nullptr; size_t poolBytes = 0, poolHead = 0; bool poolCapped = false;   // capped: already as large as the HBM budget allows
@@ -80,7 +83,7 @@ struct crt_ctx {
     uint32_t* hTileOrder[2] = {nullptr, nullptr}; hipEvent_t orderCopied[2] = {nullptr, nullptr}; hipEvent_t orderReady = nullptr; int orderFlip = 0;
     bool haveScene = false;
     // what crt_update_scene needs of the last upload: a host mirror of the geometry buffer and where each BVH's records start
-    struct Flat { int32_t kind = 0; uint64_t leafOff = 0, tlasOff = 0, tlasPairOff = 0, instOff = 0, shadeOff = 0; uint32_t tlasNodeCount = 0, maxHeight = 0;
+    struct Flat { uint64_t topOff = 0; uint32_t topCount = 0, rootRef = 0; int32_t kind = 0; uint64_t leafOff = 0, tlasOff = 0, tlasPairOff = 0, instOff = 0, shadeOff = 0; uint32_t tlasNodeCount = 0, maxHeight = 0;
                   std::vector<uint64_t> pairBase, triBase; std::vector<uint32_t> nodesUsed, triCount; std::vector<char> geom; } flat;
     char* hStage[2] = {nullptr, nullptr}; size_t stageBytes[2] = {0, 0}; hipEvent_t stageCopied[2] = {nullptr, nullptr}; int stageFlip = 0;
     hipEvent_t sceneReady = nullptr;      // recorded behind the last in-place scene update; render launches wait for it on their stream
@@ -100,7 +103,7 @@ struct crt_ctx {
     std::vector<uint8_t> latL[kLatStages + 1];          // lanes per wavefront of every tile, per stage ([0]: all 64)
     std::vector<uint32_t> latCost[kLatStages + 1];      // measured tile costs, per stage
     uint32_t* dTileCost = nullptr; uint32_t* hTileCost = nullptr; hipEvent_t costCopied = nullptr; bool costPending = false; int costStage = 0;
-    uint32_t* dBlockDesc = nullptr; uint32_t* hBlockDesc = nullptr; uint32_t nBlocks = 0, descCap = 0; hipEvent_t descReady = nullptr;
+    uint32_t* dBlockDesc = nullptr; uint32_t* hBlockDesc = nullptr; uint32_t nBlocks = 0, nBlocksWide = 0, descCap = 0; hipEvent_t descReady = nullptr;   // table = [blocks of > 8 lanes: render_tiles_kernel][narrow blocks: render_narrow_kernel]
     // Jobs (launches of several windows): what each tile costs is measured once per camera / scene by the first job launch (every wavefront's duration, scaled to
     // 64 streams); later launches dispatch the tiles most expensive first and SPLIT: see split_point
     uint32_t* dJobCost = nullptr; uint32_t* hJobCost = nullptr; hipEvent_t jobCostCopied = nullptr; bool jobCostPending = false, jobCostValid = false;
@@ -108,7 +111,7 @@ struct crt_ctx {
     double poolWindowTicks = 0;             // machine time of ONE window of this image under the pool, 100 MHz ticks (0: unknown)
     std::vector<uint32_t> jobCost;          // per local tile, 100 MHz ticks; sorted view = the tile order on the device once jobCostValid
     std::vector<uint32_t> jobOrder;
-    uint32_t* dJobDesc = nullptr; uint32_t* hJobDesc = nullptr; uint32_t jobDescCap = 0, jobBlocks = 0, jobHead = 0; hipEvent_t jobDescReady = nullptr;
+    uint32_t* dJobDesc = nullptr; uint32_t* hJobDesc = nullptr; uint32_t jobDescCap = 0, jobBlocks = 0, jobBlocksWide = 0, jobHead = 0; hipEvent_t jobDescReady = nullptr;
     uint32_t planWindows = 0, planFrames = 0; bool planPool = false, planValid = false;       // what the table on the device was planned for
     std::vector<hipEvent_t> splitEvents;    // end events of the second kernel of split launches (recycled round-robin)
     size_t splitSeq = 0; uint32_t splitLaunches = 0;
@@ -178,6 +181,32 @@ int bvh_height(crt_ctx* c, const crt_bvh& b, uint32_t* heightOut)
     }
     *heightOut = h;
     return 0;
+}
+
+// The treetop of a FileScene's BVH: its first `count` child pairs in breadth-first order from the root's pair, as a second copy whose child references name
+// treetop entries (kRefTop | index) wherever the child's own pair is in the copy too.  Same boxes, same child order: a traversal that reads these records visits
+// the reference's nodes in the reference's order.  `pairs` = the pair section, rootRef = packed reference of node 0 (interior).
+void crt_build_treetop(const crt::NodePair* pairs, uint32_t nPairs, uint32_t rootRef, crt::NodePair* top, uint32_t count)
+{
+    std::vector<uint32_t> order; order.reserve(count);
+    std::vector<uint32_t> slot(nPairs, 0xffffffffu);
+    auto pair_of = [&](uint32_t ref) -> uint32_t { return ((ref & crt::kRefOffsetMask) << 4) / 64u; };     // interior reference -> index of its child pair
+    order.push_back(pair_of(rootRef)); slot[order[0]] = 0;
+    for (size_t i = 0; i < order.size() && order.size() < count; i++)
+        for (int k = 0; k < 2 && order.size() < count; k++) {
+            const uint32_t ref = pairs[order[i]].c[k].ref;
+            if ((ref & 0xC0000000u) != crt::kRefInterior) continue;
+            const uint32_t p = pair_of(ref);
+            if (p < nPairs && slot[p] == 0xffffffffu) { slot[p] = (uint32_t)order.size(); order.push_back(p); }
+        }
+    for (uint32_t t = 0; t < count; t++) {
+        if (t >= order.size()) { memset(&top[t], 0, sizeof(crt::NodePair)); continue; }
+        top[t] = pairs[order[t]];
+        for (int k = 0; k < 2; k++) {
+            const uint32_t ref = top[t].c[k].ref;
+            if ((ref & 0xC0000000u) == crt::kRefInterior) { const uint32_t p = pair_of(ref); if (p < nPairs && slot[p] != 0xffffffffu) top[t].c[k].ref = crt::kRefTop | slot[p]; }
+        }
+    }
 }
 
 } // namespace
@@ -278,6 +307,7 @@ void crt_destroy(crt_ctx* c)
     for (auto& ev : c->evAcc) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (c->dAccOwned) (void)hipFree(c->dAccOwned);
     for (auto st : c->streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (c->narrowStream) { (void)hipStreamSynchronize(c->narrowStream); (void)hipStreamDestroy(c->narrowStream); }
     for (auto& r : c->inflight) (void)hipEventDestroy(r.freed);
     for (auto e : c->freeEvents) (void)hipEventDestroy(e);
     if (c->mustWait) (void)hipEventDestroy(c->mustWait);
@@ -347,7 +377,10 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         nPairs += b.nodesUsed / 2; nTris += b.triCount;
     }
     const uint64_t pairBytes = nPairs ? nPairs * 64 : 64;                   // offset 0 must never be a leaf record (ref 0 = "done")
-    const uint64_t leafOffB = pairBytes, leafBytes = (nTris + 1) * 48;       // +1: record fetches read 64 B from a 48-B LeafTri
+    // FileScene: a copy of the first pairs of the tree in breadth-first order (the "treetop") behind the pairs — render_narrow_kernel keeps it in LDS
+    const uint32_t topCount = (sd->kind == CRT_SCENE_FILE && sd->bvhs[0].nodesUsed >= 3u) ? (uint32_t)std::min<uint64_t>(nPairs, crt::kTreetopMaxPairs) : 0u;
+    const uint64_t topOffB = pairBytes;
+    const uint64_t leafOffB = topOffB + (uint64_t)topCount * 64, leafBytes = (nTris + 1) * 48;       // +1: record fetches read 64 B from a 48-B LeafTri
     const uint64_t tlasOffB = (leafOffB + leafBytes + 63) & ~63ull;
     const uint64_t tlasBytes = (sd->kind == CRT_SCENE_TLAS) ? (uint64_t)sd->tlasNodeCount * 32 : 0;
     const uint64_t tlasPairOffB = (tlasOffB + tlasBytes + 63) & ~63ull;      // one NodePair-shaped record per TLAS interior node (at most tlasNodeCount / 2)
@@ -438,6 +471,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         pairBase += b.nodesUsed / 2; triBase += b.triCount;
     }
     leaf[nTris].remain = 1;                                                 // pad record
+    if (topCount) crt_build_treetop(pairs, (uint32_t)nPairs, rootRef0, reinterpret_cast<crt::NodePair*>(geom.data() + topOffB), topCount);
     uint32_t tlasHeight = 0, tlasRoot = 0, tlasRoot16 = 0;
     if (sd->kind == CRT_SCENE_TLAS) {
         uint32_t nTlasPairs = 0;
@@ -527,6 +561,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     s.geom = dGeom;
     s.tlasOff = (uint32_t)tlasOffB; s.instOff = (uint32_t)instOffB; s.shadeOff = (uint32_t)shadeOffB;
     s.leafOff = (uint32_t)leafOffB; s.tlasPairOff = (uint32_t)tlasPairOffB;
+    s.topOff = (uint32_t)topOffB; s.topCount = topCount;
     s.rootRef16 = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot16 : rootRef0_16;
     s.ref16ok = (ref16ok && !getenv("CRT_DEBUG_NO_REF16")) ? 1u : 0u;
     if ((r = upload(c, mats, &s.mats))) return r;
@@ -561,6 +596,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     }
     {   // keep what crt_update_scene needs
         crt_ctx::Flat& f = c->flat;
+        f.topOff = topOffB; f.topCount = topCount; f.rootRef = rootRef0;
         f.kind = sd->kind; f.leafOff = leafOffB; f.tlasOff = tlasOffB; f.tlasPairOff = tlasPairOffB; f.instOff = instOffB; f.shadeOff = shadeOffB;
         f.tlasNodeCount = (sd->kind == CRT_SCENE_TLAS) ? sd->tlasNodeCount : 0; f.maxHeight = maxHeight;
         f.pairBase.clear(); f.triBase.clear(); f.nodesUsed.clear(); f.triCount.clear();
@@ -655,6 +691,7 @@ int crt_update_scene(crt_ctx* c, const crt_scene_desc* sd, uint32_t what)
                 for (int k = 0; k < 3; k++) { lt.v0[k] = t.vertex0[k]; lt.e1[k] = t.vertex1[k] - t.vertex0[k]; lt.e2[k] = t.vertex2[k] - t.vertex0[k]; }
             }
         }
+        if (f.topCount) crt_build_treetop(pairs, (uint32_t)(f.topOff / 64), f.rootRef, reinterpret_cast<crt::NodePair*>(f.geom.data() + f.topOff), f.topCount);   // same membership, new boxes
         touch(0, (size_t)f.tlasOff);
     }
     uint32_t tlasHeight = 0;
@@ -792,6 +829,28 @@ static size_t window_bytes(const crt_ctx* c, uint32_t passes) { return sample_by
 // CRT_LAT_POLICY="share:lanes,.." replaces stage 1 by fixed steps (tiles costing >= share x the slowest get `lanes`) and stops there.
 // one entry of a block table: local tile | first frame << 16 | log2(lanes) << 22 | window << 25 (render_tiles_kernel)
 static uint32_t block_desc(uint32_t tile, uint32_t laneBase, uint32_t lanes, uint32_t window) { uint32_t lg = 0; while ((1u << lg) < lanes) lg++; return tile | (laneBase << 16) | (lg << 22) | (window << 25); }
+// a block table in launch form: the blocks of wide wavefronts first (render_tiles_kernel), then those routed to render_narrow_kernel; both parts keep the table's
+// order (most expensive tile first).  Returns the number of wide blocks.
+// MEASURED, round 3 (tools/narrow_probe*.sh, profiles/r03_narrow_kernel.txt): render_narrow_kernel shortens a lone stream's chain — the heaviest bunny tile as 64
+// one-lane wavefronts: 13.4 ms against 17 — but two-lane wavefronts are no faster than render_tiles_kernel's (18.8 ms: each ray waits for its neighbour's
+// traversal), the chip holds fewer of its workgroups (32 KB of treetop in LDS each), and a settled single render is bound by machine time, not by its longest
+// chain: with one-lane blocks routed to it the tuned 1280x720 / 64-spp render is 21.0 ms against 20.4 - 20.9, one rank's share of an 8-way tile split 16.3 ms
+// against 17.3 - 18.3, and single stages of the tuner take 30 ms.  So nothing is routed to it unless a caller opts in (crt_config has no field for it: the
+// environment variable CRT_NARROW_LANES = 1 | 2, read per launch, is the switch the tests and the probe tools use).
+static uint32_t split_by_width(std::vector<uint32_t>& table)
+{
+    uint32_t maxNarrow = 0u;
+    if (const char* e = getenv("CRT_NARROW_LANES")) maxNarrow = std::min<uint32_t>((uint32_t)atoi(e), crt_narrow_max_lanes());
+    if (maxNarrow == 0u) return (uint32_t)table.size();
+    uint32_t limit = 3072u;                                        // 256 CUs x 12 wavefronts: all narrow blocks in flight at once, else the launch is bound by machine time
+    if (const char* e = getenv("CRT_NARROW_LIMIT")) limit = (uint32_t)atoi(e);
+    std::vector<uint32_t> wide, narrow; wide.reserve(table.size()); narrow.reserve(table.size());
+    for (uint32_t d : table) { if ((1u << ((d >> 22) & 7u)) <= maxNarrow) narrow.push_back(d); else wide.push_back(d); }
+    if (narrow.size() > limit) return (uint32_t)table.size();
+    const uint32_t nWide = (uint32_t)wide.size();
+    table.swap(wide); table.insert(table.end(), narrow.begin(), narrow.end());
+    return nWide;
+}
 static const uint32_t kLatLanes[7] = {64u, 32u, 16u, 8u, 4u, 2u, 1u};
 static const double kLatG[7] = {1.0, 0.93, 0.88, 0.79, 0.69, 0.57, 0.48};
 static int lat_index(uint32_t L) { int k = 0; while (k < 6 && kLatLanes[k] != L) k++; return k; }
@@ -824,6 +883,7 @@ static int upload_block_table(crt_ctx* c, const std::vector<uint8_t>& lanes, con
         for (uint32_t base = 0; base < 64u; base += L) table.push_back(block_desc(tl, base, L, 0u));
     }
     if (table.size() > 0x7fffffffull) return c->fail(CRT_ERR_INVALID, "block table too large");
+    c->nBlocksWide = split_by_width(table);
     if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] latency table: %zu wavefronts for %u tiles (slowest tile of the base stage %.2f ms)\n", table.size(), n, n ? cost[order[0]] * 1e-5 : 0.0);
     if (c->descCap < table.size()) {
         if (c->dBlockDesc) (void)hipFree(c->dBlockDesc);
@@ -1115,6 +1175,7 @@ static int install_job_plan(crt_ctx* c, uint32_t windows, uint32_t frames, bool 
     if (c->planValid && c->planWindows == windows && c->planFrames == frames && c->planPool == pool) return 0;
     std::vector<uint32_t> table; uint32_t head = 0;
     plan_job(c, windows, frames, pool, table, &head);
+    c->jobBlocksWide = split_by_width(table);
     c->planValid = true; c->planWindows = windows; c->planFrames = frames; c->planPool = pool; c->jobHead = head; c->jobBlocks = (uint32_t)table.size();
     if (table.empty()) return 0;
     if (c->jobDescCap < table.size()) {
@@ -1225,27 +1286,52 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
                 c->recWaves = pool ? c->tileCount * ((nf + crt_pool_streams(nf) - 1u) / crt_pool_streams(nf)) : c->tileCount * windows;
                 c->recResident = pool ? 4096u : 5120u;                            // 4 / 5 wavefronts per SIMD (render_pool_kernel / render_tiles_kernel)
             }
+            // a second kernel of the same launch on another stream: released by the launch's start event, joined before its end event
+            auto join = [&](hipStream_t other) -> hipError_t {
+                if (other == st) return hipSuccess;
+                hipError_t e = hipSuccess;
+                if (c->splitEvents.size() < 32) { hipEvent_t ne; e = hipEventCreateWithFlags(&ne, hipEventDisableTiming); if (e == hipSuccess) c->splitEvents.push_back(ne); }
+                if (e == hipSuccess) { hipEvent_t je = c->splitEvents[c->splitSeq++ % c->splitEvents.size()]; e = hipEventRecord(je, other); if (e == hipSuccess) e = hipStreamWaitEvent(st, je, 0); }
+                return e;
+            };
+            // a block table = [wide blocks: render_tiles_kernel on this launch's stream][blocks of <= 8 lanes: render_narrow_kernel on the next stream, submitted first —
+            // they are the most expensive tiles' and the launch ends on them]
+            auto launch_table = [&](const uint32_t* desc, uint32_t nAll, uint32_t nWide, uint32_t* cost) -> hipError_t {
+                hipError_t e = hipSuccess;
+                hipStream_t sn = st;
+                if (nAll > nWide) {
+                    if (!c->narrowStream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); e = hipStreamCreateWithPriority(&c->narrowStream, hipStreamNonBlocking, hi); if (e != hipSuccess) return e; }
+                    sn = c->narrowStream;
+                    e = hipStreamWaitEvent(sn, ev.a, 0);
+                    if (e == hipSuccess) e = crt_launch_render_narrow(&c->hScene, slab, c->dCounters, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                                                      spp_first + f0 * passes, nf, passes, c->ldsBytes, desc + nWide, nAll - nWide, cost, sn);
+                }
+                if (e == hipSuccess && nWide)
+                    e = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                          spp_first + f0 * passes, nf, passes, c->ldsBytes, 0, desc, nWide, cost, 0u, nullptr, st);
+                if (e == hipSuccess) e = join(sn);                                 // (after both are submitted: the two kernels run side by side)
+                return e;
+            };
             if (pool) {
                 void* scratch = (char*)slab + (size_t)windows * sample_bytes_per_window(c, passes);
                 hipStream_t st2 = st;
                 if (jobBlocks) {
                     // the expensive tiles first, through the block table, on this launch's stream; the pool for the rest on the next stream, released by the same start event
+                    le = launch_table(c->dJobDesc, jobBlocks, c->jobBlocksWide, nullptr);
                     st2 = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
-                    le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                           spp_first + f0 * passes, nf, passes, c->ldsBytes, 0, c->dJobDesc, jobBlocks, nullptr, 0u, nullptr, st);
-                    if (le == hipSuccess) le = hipStreamWaitEvent(st2, ev.a, 0);
+                    if (le == hipSuccess && st2 != st) le = hipStreamWaitEvent(st2, ev.a, 0);
                 }
                 if (le == hipSuccess)
                     le = crt_launch_render_pool(&c->hScene, slab, scratch, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
                                                 spp_first + f0 * passes, nf, passes, c->cfg.collectStats, jobBlocks ? head : 0u, wantJobCost ? c->dJobCost : nullptr, jobClk, st2);
-                if (jobBlocks && le == hipSuccess) {
-                    if (c->splitEvents.size() < 32) { hipEvent_t e; le = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (le == hipSuccess) c->splitEvents.push_back(e); }
-                    if (le == hipSuccess) { hipEvent_t e = c->splitEvents[c->splitSeq++ % c->splitEvents.size()]; le = hipEventRecord(e, st2); if (le == hipSuccess) le = hipStreamWaitEvent(st, e, 0); }
-                }
+                if (jobBlocks && le == hipSuccess) le = join(st2);
+            } else if (jobBlocks) {
+                le = launch_table(c->dJobDesc, jobBlocks, c->jobBlocksWide, nullptr);
+            } else if (blockDesc && nBlocks) {
+                le = launch_table(blockDesc, nBlocks, c->nBlocksWide, wantCost ? c->dTileCost : nullptr);
             } else {
-                const bool job = jobBlocks != 0u;
                 le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, job ? c->dJobDesc : blockDesc, job ? jobBlocks : nBlocks,
+                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, nullptr, 0u,
                                        wantCost ? c->dTileCost : (wantJobCost ? c->dJobCost : nullptr), 0u, jobClk, st);
             }
             if (jobBlocks && le == hipSuccess) c->splitLaunches++;

@@ -27,6 +27,10 @@ constexpr uint32_t kRefReturn = 0xFFFFFFFFu;
 constexpr uint32_t kRefDone = 0u;
 constexpr uint32_t kRefOffsetMask = 0x3fffffffu;
 constexpr uint64_t kMaxGeomBytes = 1ull << 32;     // 32-bit byte offsets
+// render_narrow_kernel only (FileScene): a reference inside the treetop copy (Scene::topOff) — bits 31..30 = 01 (the TLAS-interior tag, unused in a single-level
+// scene), bits 0..29 = index of the treetop entry
+constexpr uint32_t kRefTop = 0x40000000u;
+constexpr uint64_t kTreetopMaxPairs = 512;         // 32 KB of LDS per workgroup of four narrow wavefronts
 
 // 16-bit form of the same reference (`ref16`), used by render_pool_kernel for `cur` and for its traversal stack (2 bytes per entry: LDS is
 // what limits the waves per SIMD): the same tags in bits 15..14 and a record INDEX in bits 13..0 instead of an offset
@@ -96,6 +100,7 @@ struct Scene {                            // passed to the kernels BY VALUE (ker
     uint32_t stackDepth;                  // dwords per lane of the LDS traversal stack (BVH height + TLAS height + 1 marker + slack)
     uint32_t bvhStack;                    // of which the BVH part (find_nearest_kernel keeps the TLAS entries above it)
     uint32_t lightAxis, floorAxisY;       // 1: light invT has an identity rotation block / floor normal is exactly (0,1,0): short quad / plane tests (kernels.hip)
+    uint32_t topOff, topCount;            // FileScene: the treetop (first child pairs in breadth-first order, references rewritten: kRefTop) inside geom; 0 pairs: none
     uint32_t rootIsPair;                  // 1: rootPair holds the root's two children (always, unless the root itself is a leaf)
     float rootPair[16];                   // NodePair of the root (BVH: its child pair; TLAS: its two child TlasNodes, same 2 x {lo, ref, hi, -} layout)
 };

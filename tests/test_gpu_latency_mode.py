@@ -79,3 +79,22 @@ def test_mixed_sequence_of_launch_shapes_and_camera_moves(crt, orc):
         if step % 5 == 4: ctx.timing()
         o.set_camera_state(*cam); o.clear(); o.set_spp(1); o.set_params(5, passes); o.render(frames, 4)
         assert np.array_equal(ctx.accumulator(), o.accumulator()), (step, frames, passes)
+
+
+@pytest.mark.parametrize("xml,kind,lanes", [("bunny_scene.xml", 0, 1), ("bunny_scene.xml", 0, 2), ("tlas_scene.xml", 1, 2)])
+def test_narrow_kernel_renders_the_same_pixels(crt, orc, monkeypatch, xml, kind, lanes):
+    """render_narrow_kernel (opt-in: CRT_NARROW_LANES) takes the one- / two-lane blocks of a table: plain per-lane path loops, both children's records requested
+    ahead, record stack and treetop in LDS — the pixels must be the oracle's whatever share of the tiles it renders"""
+    W, H, frames = 96, 64, 64
+    want = _oracle(orc, xml, kind, W, H, frames, 1)
+    hs = crt.HostScene(scene_path(xml), kind, ASSETS)
+    monkeypatch.setenv("CRT_RENDER_KERNEL", "tiles")
+    monkeypatch.setenv("CRT_NARROW_LANES", str(lanes))
+    monkeypatch.setenv("CRT_LAT_FORCE", "1")
+    for policy in ("0:1", "0.5:2,0:32", "0.6:1,0.3:2"):
+        monkeypatch.setenv("CRT_LAT_POLICY", policy)
+        ctx = crt.Context(W, H); hs.upload(ctx)
+        for i in range(4):
+            ctx.clear(); ctx.render(1, frames, 1); ctx.sync()
+            assert np.array_equal(ctx.accumulator(), want), (policy, i)
+        ctx.close()

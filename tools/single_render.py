@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Single-render latency (clear, crt_render(1, 64, 1), sync) over the tuner's whole sequence: first render, untuned, every stage, settled median.
+    python tools/single_render.py [scene.xml kind W H [renders]]"""
+import importlib.util, json, os, sys, time
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))
+crt = importlib.util.module_from_spec(spec); spec.loader.exec_module(crt)
+A = os.path.join(REPO, "assets")
+a = sys.argv[1:]
+xml, kind = (a[0], int(a[1])) if len(a) > 1 else ("bunny_scene.xml", 0)
+W, H = (int(a[2]), int(a[3])) if len(a) > 3 else (1280, 720)
+n = int(a[4]) if len(a) > 4 else 20
+sc = crt.HostScene(os.path.join(A, "scenes", xml), kind, A)
+ctx = crt.Context(W, H); sc.upload(ctx); ctx.reserve(64, 1)
+ts = []
+for i in range(n):
+    ctx.clear(); ctx.sync(); t0 = time.perf_counter(); ctx.render(1, 64, 1); ctx.sync(); ts.append((time.perf_counter() - t0) * 1e3)
+print(json.dumps({"scene": xml, "size": [W, H], "renders_ms": [round(t, 2) for t in ts], "first_ms": round(ts[0], 2), "settled_ms": round(float(np.median(ts[-5:])), 2), "best_ms": round(min(ts), 2)}))
