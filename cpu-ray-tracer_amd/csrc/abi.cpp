@@ -22,6 +22,7 @@ extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
 extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t*, unsigned long long*, hipStream_t);
 extern "C" uint32_t crt_pool_streams(uint32_t frames);
 extern "C" uint32_t crt_narrow_max_lanes(void);
+extern "C" hipError_t crt_launch_probe(const crt::Scene*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, hipStream_t);
 extern "C" hipError_t crt_launch_render_narrow(const crt::Scene*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
@@ -100,6 +101,7 @@ struct crt_ctx {
     bool latDone = false;          // all stages measured, the fastest one's table is (being) installed
     bool latConfirming = false; std::vector<int> latQueue;      // after the last stage: the two fastest stages are timed once more
     bool latWarm = false;          // stage 0 has been measured once already (the first launch after an upload runs cold: it is measured twice)
+    bool latProbed = false;        // the cost probe has run for this camera / scene: stage 0 is a block table built from its estimates (latL[0]), not one wavefront per tile
     std::vector<uint8_t> latL[kLatStages + 1];          // lanes per wavefront of every tile, per stage ([0]: all 64)
     std::vector<uint32_t> latCost[kLatStages + 1];      // measured tile costs, per stage
     uint32_t* dTileCost = nullptr; uint32_t* hTileCost = nullptr; hipEvent_t costCopied = nullptr; bool costPending = false; int costStage = 0;
@@ -806,7 +808,7 @@ static int update_tile_order(crt_ctx* c)
     }
     // a new camera / scene: the latency mode measures again (see next_block_table)
     for (int k = 0; k <= crt_ctx::kLatStages; k++) { c->tuneCount[k] = 0; c->tuneMs[k] = 0; }
-    c->latStage = 0; c->latBest = 0; c->latDone = false; c->latWarm = false; c->latConfirming = false; c->latQueue.clear(); c->costPending = false;
+    c->latStage = 0; c->latBest = 0; c->latDone = false; c->latWarm = false; c->latConfirming = false; c->latQueue.clear(); c->costPending = false; c->latProbed = false;
     first.insert(first.end(), rest.begin(), rest.end());
     c->jobCostValid = false; c->jobCostPending = false; c->planValid = false;
     { const int r = upload_tile_order(c, first); if (r) return r; }
@@ -910,7 +912,7 @@ static int next_block_table(crt_ctx* c)
     const int s = c->costStage;
     if (s == 0 && !c->latWarm) { c->latWarm = true; return 0; }          // measure the one-wave launch once more, warm
     c->latCost[s].assign(c->hTileCost, c->hTileCost + n);
-    if (s == 0) c->latL[0].assign(n, 64);
+    if (s == 0 && !c->latProbed) c->latL[0].assign(n, 64);
     if (c->tuneCount[s] && (c->latBest == s || !c->tuneCount[c->latBest] || c->tuneMs[s] < c->tuneMs[c->latBest])) c->latBest = s;
     bool last = s >= K;
     std::vector<std::pair<double, uint32_t>> steps;
@@ -923,8 +925,8 @@ static int next_block_table(crt_ctx* c)
         }
         if (s >= 1) last = true;
     }
-    auto install = [&](int stage) -> int {                                  // the table of an earlier stage back onto the device (stage 0 needs none)
-        if (stage != 0 && stage != c->latStage) { const int r = upload_block_table(c, c->latL[stage], c->latCost[stage]); if (r) return r; }
+    auto install = [&](int stage) -> int {                                  // the table of an earlier stage back onto the device (an unprobed stage 0 needs none)
+        if ((stage != 0 || c->latProbed) && stage != c->latStage) { const int r = upload_block_table(c, c->latL[stage], c->latCost[stage]); if (r) return r; }
         c->latStage = stage; return 0;
     };
     auto fastest = [&](int except) { int b = -1; for (int k = 0; k <= K; k++) if (k != except && c->tuneCount[k] && (b < 0 || c->tuneMs[k] < c->tuneMs[b])) b = k; return b; };
@@ -955,7 +957,7 @@ static int next_block_table(crt_ctx* c)
         for (uint32_t i = 0; i < n; i++)
             for (const auto& st : steps) if (top > 0 && (double)baseC[i] >= st.first * (double)top) { L[i] = (uint8_t)st.second; break; }
     } else {
-        double aim = s == 0 ? 0.64 : 0.92;
+        double aim = (s == 0 && !c->latProbed) ? 0.64 : 0.92;               // (a probed stage 0 is a narrowed table already: refine, do not halve again)
         if (const char* e = getenv("CRT_LAT_AIM")) { const double v = atof(e); if (s > 0 && v > 0) aim = v; }
         for (uint32_t i = 0; i < n; i++) L[i] = next_lanes(baseL[i], baseC[i], aim * (double)top);
     }
@@ -1194,6 +1196,36 @@ static int install_job_plan(crt_ctx* c, uint32_t windows, uint32_t frames, bool 
     return 0;
 }
 
+// The first single-window launch after a camera / scene change used to run one wavefront per tile (34 ms for the 720p bunny) because nothing was known about the
+// tiles.  Now a probe launch (render_narrow_kernel<.., true>: 64 paths per tile, ~0.3 ms) counts the steps those paths take and stage 0 of the latency mode is a
+// block table built from that estimate.  The call waits for the probe (the only host wait of crt_render, once per camera / scene).
+static int probe_tile_costs(crt_ctx* c, hipStream_t st)
+{
+    const uint32_t n = c->tileCount;
+    if (!c->dTileCost) {
+        HIPCK(c, hipMalloc((void**)&c->dTileCost, (size_t)n * 4));
+        HIPCK(c, hipHostMalloc((void**)&c->hTileCost, (size_t)n * 4, hipHostMallocDefault));
+        HIPCK(c, hipEventCreateWithFlags(&c->costCopied, hipEventDisableTiming));
+    } else HIPCK(c, hipEventSynchronize(c->costCopied));                   // an earlier measurement that a camera change abandoned
+    HIPCK(c, crt_launch_probe(&c->hScene, c->tileFirst, c->tileStride, n, (uint32_t)c->tilesX, c->dTileCost, st));
+    HIPCK(c, hipMemcpyAsync(c->hTileCost, c->dTileCost, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCK(c, hipEventRecord(c->costCopied, st));
+    HIPCK(c, hipStreamSynchronize(st));
+    // steps of 64 paths -> an estimate in the units the tuner's model uses: only ratios matter (aims are fractions of the most expensive tile)
+    std::vector<uint32_t>& est = c->latCost[0]; est.assign(c->hTileCost, c->hTileCost + n);
+    // "the most expensive tile" of a 64-path estimate is an outlier of its noise: the aim refers to the 98th percentile instead
+    uint32_t top = 0;
+    { std::vector<uint32_t> sorted(est); const size_t k = (size_t)((double)n * 0.98); std::nth_element(sorted.begin(), sorted.begin() + std::min<size_t>(k, n - 1), sorted.end()); top = sorted[std::min<size_t>(k, n - 1)]; }
+    std::vector<uint8_t>& L = c->latL[0]; L.assign(n, 64);
+    double aim = 0.90;
+    if (const char* e = getenv("CRT_LAT_PROBE_AIM")) aim = atof(e);
+    if (top > 0) for (uint32_t i = 0; i < n; i++) L[i] = next_lanes(64, est[i], aim * (double)top);
+    c->latProbed = true;
+    bool any = false; for (uint32_t i = 0; i < n; i++) any = any || L[i] != 64;
+    if (!any) { c->latProbed = false; return 0; }                           // nothing to narrow: stage 0 stays one wavefront per tile
+    return upload_block_table(c, L, est);
+}
+
 int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
 {
     if (!c) return CRT_ERR_INVALID;
@@ -1232,8 +1264,9 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         const bool gpuIdle = !c->lastRenderEnd || hipEventQuery(c->lastRenderEnd) == hipSuccess;
         if (nf <= 64u && nf >= 8u && gpuIdle && !c->cfg.collectStats && c->tileCount <= 0x10000u && !getenv("CRT_LAT_OFF")) {
             if (c->costPending && hipEventQuery(c->costCopied) == hipSuccess) { c->costPending = false; harvest_tuning(c); if ((r = next_block_table(c))) return r; }
+            if (c->latStage == 0 && !c->latProbed && !c->latWarm && !c->costPending && nf == 64u && !getenv("CRT_LAT_POLICY") && !getenv("CRT_LAT_NO_PROBE")) { if ((r = probe_tile_costs(c, st))) return r; }
             const int stage = c->latStage;
-            if (stage) { blockDesc = c->dBlockDesc; nBlocks = c->nBlocks; HIPCK(c, hipStreamWaitEvent(st, c->descReady, 0)); }
+            if (stage || c->latProbed) { blockDesc = c->dBlockDesc; nBlocks = c->nBlocks; HIPCK(c, hipStreamWaitEvent(st, c->descReady, 0)); }
             wantCost = (!c->latDone && !c->costPending) || (c->latDone && getenv("CRT_LAT_RECORD"));      // (the latter: diagnostics, crt_debug_tile_costs)
             c->evRender.back().mode = c->latDone ? -1 : stage;
             if (wantCost && !c->latDone) c->costStage = stage;

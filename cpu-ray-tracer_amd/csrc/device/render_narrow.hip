@@ -33,7 +33,10 @@ __device__ __host__ __forceinline__ uint32_t narrow_lane_dwords(uint32_t stackDe
 
 constexpr uint32_t kNarrowWaves = 4u;                      // wavefronts per workgroup: they share the treetop in LDS, each renders one block of the table
 
-template <int KIND>
+// PROBE = true is the cost probe of the latency mode (abi.cpp probe_tile_costs): one wavefront per tile, lane l traces ONE path through pixel (2 (l % 8), 2 (l / 8)) of the
+// tile with a seed of its own, nothing is stored, and the wavefront leaves the number of traversal / shading steps its 64 paths took in tileCost[tile] — an estimate of
+// what the tile's streams will cost (a stream = 256 such paths), available ~0.3 ms after a camera or scene change instead of after a first full render.
+template <int KIND, bool PROBE>
 __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, float4* __restrict__ slab, Counters* __restrict__ counters,
                                                               uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                               uint32_t sppFirst, uint32_t frames, uint32_t passes,
@@ -45,8 +48,8 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
     const char* __restrict__ geom = sc.geom;
     // the treetop into LDS, by all 256 threads (FileScene only)
     const rec4* ldsTop = reinterpret_cast<const rec4*>(ldsAll);
-    const uint32_t topDwords = (KIND == 0) ? sc.topCount * 16u : 0u;
-    if (KIND == 0 && sc.topCount) {
+    const uint32_t topDwords = (KIND == 0 && !PROBE) ? sc.topCount * 16u : 0u;
+    if (KIND == 0 && !PROBE && sc.topCount) {
         rec4* dst = reinterpret_cast<rec4*>(ldsAll);
         for (uint32_t i = threadIdx.x; i < sc.topCount * 4u; i += 256u) dst[i] = ldg(geom, sc.topOff + i * 16u);
         __syncthreads();
@@ -54,9 +57,9 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
     // blockDesc[block] = local tile index | first frame << 16 | log2(lanes) << 22 | window << 25 (the table format of render_tiles_kernel; abi.cpp)
     const uint32_t entry = blockIdx.x * kNarrowWaves + wave;
     if (entry >= nBlocks) return;
-    const uint32_t d = blockDesc[entry];
+    const uint32_t d = PROBE ? (entry | (6u << 22)) : blockDesc[entry];          // (probe: block = tile, all 64 lanes)
     const uint32_t tl = d & 0xffffu, laneBase = (d >> 16) & 63u, myLanes = 1u << ((d >> 22) & 7u), win = d >> 25;
-    if (tl >= tileCount || myLanes > kNarrowMaxLanes) return;
+    if (tl >= tileCount || (!PROBE && myLanes > kNarrowMaxLanes)) return;
     sppFirst += win * 64u * passes;
     frames = (frames - win * 64u < 64u) ? frames - win * 64u : 64u;               // frames of THIS window (the last one may be partial)
     frames = frames > laneBase ? ((frames - laneBase < myLanes) ? frames - laneBase : myLanes) : 0u;
@@ -65,15 +68,17 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     // this wavefront's LDS behind the treetop
-    uint32_t* lds = ldsAll + topDwords + wave * ((KIND == 0) ? kNarrowMaxLanes * narrow_lane_dwords(sc.stackDepth) : (sc.stackDepth + 15u) * 64u);
+    uint32_t* lds = ldsAll + topDwords + wave * ((KIND == 0 && !PROBE) ? kNarrowMaxLanes * narrow_lane_dwords(sc.stackDepth) : (sc.stackDepth + 15u) * 64u);
 
     uint32_t nRays = 0, nPrimary = 0, nMesh = 0;
-    const uint32_t items = 256u * passes;                                         // (pixel, pass) pairs in stream order
+    const uint32_t items = PROBE ? 1u : 256u * passes;                            // (pixel, pass) pairs in stream order
     uint32_t seed = init_seed(tx + ty * (uint32_t)sc.W + (sppFirst + (laneBase + lane) * passes) * 1799u);   // renderer.cpp:120
+    if (PROBE) seed = init_seed(0x9e3779b9u ^ (tile * 64u + lane));
+    uint32_t steps = 0;                                                           // probe: traversal + weighted shading steps of this lane's path
 
     // LDS of this lane
     uint32_t* refStk; rec4* recStk; float* fst; uint32_t* seqStk = nullptr; uint32_t fstStride;
-    if (KIND == 0) {
+    if (KIND == 0 && !PROBE) {
         uint32_t* mine = lds + lane * narrow_lane_dwords(sc.stackDepth);
         recStk = reinterpret_cast<rec4*>(mine); refStk = mine + sc.stackDepth * 16u; fst = reinterpret_cast<float*>(refStk + sc.stackDepth); fstStride = 1u;
     } else {
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
 
     for (uint32_t item = 0; item < items; item++) {
         // ---------------- ProcessTile + Camera::GetPrimaryRay (renderer.cpp:125-126, camera.h:23-30) ----------------
-        const uint32_t pix = (passes == 1u) ? item : item / passes;
+        const uint32_t pix = PROBE ? ((lane & 7u) * 2u + (lane >> 3) * 32u) : ((passes == 1u) ? item : item / passes);
         const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
         const float jy = rnd(seed);                                               // pinned: first draw is the y jitter
         const float jx = rnd(seed);
@@ -104,10 +109,11 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
             const f3 rD = rcp_exact3(D);
             Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
             nRays++;
-            if (KIND == 1) {
+            if (KIND == 1 || PROBE) {
                 Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
                 int traversed = 0, tested = 0;
                 find_nearest_seq(sc, O, D, rD, h, seqStk, cn, traversed, tested);
+                if (PROBE) steps += cn.interior + cn.tri + cn.tlas + 3u;          // a shading step weighs about three traversal steps
             } else {
                 hit_light_floor(sc, O, D, h);
                 // ---- BVH::IntersectBVH (bvh.cpp:224-258): ordered, stack-based; `q` = the record of `cur`.  References: kRefInterior | offset (pair in HBM / L2),
@@ -256,10 +262,13 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
 #pragma unroll
         for (int k = 4; k >= 0; k--)
             if (depth > k) { const float* fd = fst + (uint32_t)(3 * k) * fstStride; L = mk3(fd[0], fd[fstStride], fd[2u * fstStride]) * L; }
-        uint32_t pass = 0;
-        if (passes != 1u) pass = item - pix * passes;
-        slab[((size_t)tl * 256u + pix) * (64u * passes) + ((laneBase + lane) * passes + pass)] = make_float4(L.x, L.y, L.z, 0.0f);
+        if (!PROBE) {
+            uint32_t pass = 0;
+            if (passes != 1u) pass = item - pix * passes;
+            slab[((size_t)tl * 256u + pix) * (64u * passes) + ((laneBase + lane) * passes + pass)] = make_float4(L.x, L.y, L.z, 0.0f);
+        } else if (L.x != L.x) steps++;                                            // (keeps the probe's shading arithmetic alive)
     }
+    if (PROBE) { const uint32_t sum = wave_sum(steps); if (lane == 0) tileCost[tl] = sum; return; }
     // what this tile cost (100 MHz wall clock ticks; the longest of its wavefronts): the host's latency mode sizes the next launch's wavefronts with it
     if (tileCost && lane == 0) atomicMax(&tileCost[tl], (uint32_t)(wall_clock64() - clk0));
     atomicAdd(&counters->v[0], (unsigned long long)nRays);
@@ -280,8 +289,19 @@ extern "C" hipError_t crt_launch_render_narrow(const crt::Scene* sc, void* slab,
     dim3 grid((nBlocks + crt::kNarrowWaves - 1u) / crt::kNarrowWaves), block(64u * crt::kNarrowWaves);
     if (sc->kind == 0) {
         const uint32_t ldsBytes = sc->topCount * 64u + crt::kNarrowWaves * crt::kNarrowMaxLanes * crt::narrow_lane_dwords(sc->stackDepth) * 4u;
-        hipLaunchKernelGGL((crt::render_narrow_kernel<0>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, blockDesc, nBlocks, tileCost);
+        hipLaunchKernelGGL((crt::render_narrow_kernel<0, false>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, blockDesc, nBlocks, tileCost);
     } else
-        hipLaunchKernelGGL((crt::render_narrow_kernel<1>), grid, block, crt::kNarrowWaves * (sc->stackDepth + 15u) * 64u * 4u, stream, *sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, blockDesc, nBlocks, tileCost);
+        hipLaunchKernelGGL((crt::render_narrow_kernel<1, false>), grid, block, crt::kNarrowWaves * (sc->stackDepth + 15u) * 64u * 4u, stream, *sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, blockDesc, nBlocks, tileCost);
+    return hipGetLastError();
+}
+
+// the latency mode's cost probe: one wavefront per owned tile, 64 paths each, step counts into tileCost[tile] (overwritten)
+extern "C" hipError_t crt_launch_probe(const crt::Scene* sc, uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t* tileCost, hipStream_t stream)
+{
+    if (tileCount == 0 || !tileCost || tileCount > 0x10000u) return hipSuccess;
+    dim3 grid((tileCount + crt::kNarrowWaves - 1u) / crt::kNarrowWaves), block(64u * crt::kNarrowWaves);
+    const uint32_t ldsBytes = crt::kNarrowWaves * (sc->stackDepth + 15u) * 64u * 4u;
+    if (sc->kind == 0) hipLaunchKernelGGL((crt::render_narrow_kernel<0, true>), grid, block, ldsBytes, stream, *sc, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, tileCount, tileCost);
+    else hipLaunchKernelGGL((crt::render_narrow_kernel<1, true>), grid, block, ldsBytes, stream, *sc, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, tileCount, tileCost);
     return hipGetLastError();
 }

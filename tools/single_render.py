@@ -13,6 +13,9 @@ W, H = (int(a[2]), int(a[3])) if len(a) > 3 else (1280, 720)
 n = int(a[4]) if len(a) > 4 else 20
 sc = crt.HostScene(os.path.join(A, "scenes", xml), kind, A)
 ctx = crt.Context(W, H); sc.upload(ctx); ctx.reserve(64, 1)
+# warm the process (code objects, slab pool) with another camera, then measure from a camera change on: first_ms = the first render after it
+ctx.set_camera_state((0.3, 0.2, -2.2), (0.0, 0.0, 1.0)); ctx.render(1, 64, 1); ctx.sync()
+ctx.set_camera_state((0.0, 0.0, -2.0), (0.0, 0.0, -1.0))
 ts = []
 for i in range(n):
     ctx.clear(); ctx.sync(); t0 = time.perf_counter(); ctx.render(1, 64, 1); ctx.sync(); ts.append((time.perf_counter() - t0) * 1e3)
