@@ -110,6 +110,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (there is no fallback path)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
+        # the library's test / diagnostic environment switches (CRT_RENDER_KERNEL, CRT_LAT_*, ...) are dead unless the process opts in; the test suite and the
+        # tools do (tests/conftest.py, tools/*.py set CRT_ENABLE_DEBUG_HOOKS=1 for themselves), bench.py and a host application do not
+        if os.environ.get("CRT_ENABLE_DEBUG_HOOKS") == "1":
+            L.crt_debug_enable_hooks(1)
         L.crt_last_error.restype = C.c_char_p
         L.crt_last_error.argtypes = [C.c_void_p]
         L.crt_host_last_error.restype = C.c_char_p
@@ -223,7 +227,7 @@ class Context:
         return hits
 
     def upload_desc(self, kind, bvhs, textures, floor_texture, sky_texture, materials, light_T, light_invT, light_size=0.5,
-                    floor_n=(0, 1, 0), floor_d=1.0, floor_invto=None, obj_mat_idx=None, tlas_nodes=None):
+                    floor_n=(0, 1, 0), floor_d=1.0, floor_invto=None, obj_mat_idx=None, tlas_nodes=None, update_what=None):
         """crt_upload_scene with arrays BUILT ELSEWHERE, in the reference's own layouts (INTEGRATION.md path A): bvhs = dicts with `nodes` (32-byte BVHNode
         records), `tris` (112-byte Tri records), `triIndices` (uint32) and, for two-level scenes, objIdx / matIdx / T / invT; textures = uint32 (h, w)
         arrays of 0x00RRGGBB texels; materials = (reflectivity, refractivity, absorption[3], texture index or -1).  Nothing of the repo's host front is involved."""
@@ -256,6 +260,9 @@ class Context:
         if floor_invto is None:                                              # file_scene.cpp:16: Plane(.., texW / 100) with an integer division
             floor_invto = 1.0 / float(max(int(textures[floor_texture].shape[1]) // 100, 1)) if 0 <= floor_texture < len(textures) else 1.0
         d.floorInvto = floor_invto
+        if update_what is not None:                                          # the same description to crt_update_scene (in-place update of the uploaded scene)
+            self._ck(self.L.crt_update_scene(self.h, C.byref(d), C.c_uint32(update_what)))
+            return
         self._ck(self.L.crt_upload_scene(self.h, C.byref(d)))
 
     def find_nearest(self, O, D, inside=None):

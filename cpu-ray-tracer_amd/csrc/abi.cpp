@@ -50,6 +50,12 @@ namespace {
 
 thread_local std::string g_createError;
 
+// Test / diagnostic switches (CRT_RENDER_KERNEL, CRT_LAT_*, CRT_SPLIT_*, CRT_DEBUG_*, CRT_NARROW_*, CRT_PLAN_*) are environment variables that are looked at
+// ONLY after the process has called crt_debug_enable_hooks(1) — the test suite and the tools do, a host application never does, so a variable that happens to be
+// exported in its environment cannot change what the library does.
+bool g_hooks = false;
+inline const char* hook(const char* name) { return g_hooks ? getenv(name) : nullptr; }
+
 struct EventPair { hipEvent_t a, b; int mode = -1; bool seen = false; };   // mode: latency-mode tag of a single-window launch (0 wide, 1 narrow), -1 otherwise
 
 } // namespace
@@ -217,6 +223,8 @@ extern "C" {
 
 int crt_abi_version(void) { return CRT_ABI_VERSION; }
 
+void crt_debug_enable_hooks(int on) { g_hooks = on != 0; }
+
 int crt_device_count(void)
 {
     int n = 0;
@@ -244,7 +252,7 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     if (cfg->device < 0 || cfg->device >= ndev) { g_createError = "crt_create: device ordinal out of range"; return CRT_ERR_INVALID; }
     crt_ctx* c = new crt_ctx();
     c->cfg = *cfg;
-    if (const char* k = getenv("CRT_RENDER_KERNEL")) {             // tests / A-B runs: "tiles" = never the stream pool, "pool_always" = also for launches of <= 64 frames
+    if (const char* k = hook("CRT_RENDER_KERNEL")) {             // tests / A-B runs: "tiles" = never the stream pool, "pool_always" = also for launches of <= 64 frames
         c->usePool = strcmp(k, "tiles") != 0;
         if (!strcmp(k, "pool_always")) c->poolMinWaves = 0;
     }
@@ -552,7 +560,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         const float* m = sd->lightInvT;
         s.lightAxis = (m[0] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f && m[5] == 1.0f && m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f && m[10] == 1.0f) ? 1u : 0u;
         s.floorAxisY = (sd->floorN[0] == 0.0f && sd->floorN[1] == 1.0f && sd->floorN[2] == 0.0f) ? 1u : 0u;
-        if (getenv("CRT_DEBUG_GENERAL_PRIMS")) s.lightAxis = s.floorAxisY = 0u;     // tests: the general quad / plane expressions on the standard scenes
+        if (hook("CRT_DEBUG_GENERAL_PRIMS")) s.lightAxis = s.floorAxisY = 0u;     // tests: the general quad / plane expressions on the standard scenes
     }
     s.floorMat = mats[1];
     s.skyOffset = texOff[sd->skyTexture]; s.skyW = sd->textures[sd->skyTexture].width; s.skyH = sd->textures[sd->skyTexture].height;
@@ -565,7 +573,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     s.leafOff = (uint32_t)leafOffB; s.tlasPairOff = (uint32_t)tlasPairOffB;
     s.topOff = (uint32_t)topOffB; s.topCount = topCount;
     s.rootRef16 = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot16 : rootRef0_16;
-    s.ref16ok = (ref16ok && !getenv("CRT_DEBUG_NO_REF16")) ? 1u : 0u;
+    s.ref16ok = (ref16ok && !hook("CRT_DEBUG_NO_REF16")) ? 1u : 0u;
     if ((r = upload(c, mats, &s.mats))) return r;
     s.rootRef = (sd->kind == CRT_SCENE_TLAS) ? tlasRoot : rootRef0;
     // Traversal stack entries (LDS is what limits the waves per SIMD, so no slack): the ordered traversal keeps at most one pending sibling per level
@@ -583,10 +591,10 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
         memcpy(s.rootPair, geom.data() + ((size_t)(rootRef0 & crt::kRefOffsetMask) << 4), 64);
         s.rootIsPair = 1;
     }
-    if (getenv("CRT_DEBUG_NO_ROOTPAIR")) s.rootIsPair = 0;                            // tests: every ray starts at the root reference instead
+    if (hook("CRT_DEBUG_NO_ROOTPAIR")) s.rootIsPair = 0;                            // tests: every ray starts at the root reference instead
     s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 1 : 0);   // + TLAS pushes + the return marker
     c->ldsBytes = s.stackDepth * 64u * 4u;
-    if (const char* e = getenv("CRT_DEBUG_EXTRA_LDS")) c->ldsBytes += (uint32_t)atoi(e);   // occupancy experiments only
+    if (const char* e = hook("CRT_DEBUG_EXTRA_LDS")) c->ldsBytes += (uint32_t)atoi(e);   // occupancy experiments only
     if (c->ldsBytes + 15u * 256u > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "tree height %u (+TLAS %u) needs %u bytes of LDS traversal stack per wave (> 64 KiB)", maxHeight, tlasHeight, c->ldsBytes);
     // world-space bounds of all meshes (FileScene: root box of the BVH; TLAS: root box of the TLAS) for the dispatch-order heuristic
     {
@@ -656,7 +664,7 @@ static void set_root(crt_ctx* c, int kind, const float* lo, const float* hi)
         memcpy(s.rootPair, f.geom.data() + ((size_t)(s.rootRef & crt::kRefOffsetMask) << 4), 64);
         s.rootIsPair = 1;
     }
-    if (getenv("CRT_DEBUG_NO_ROOTPAIR")) s.rootIsPair = 0;
+    if (hook("CRT_DEBUG_NO_ROOTPAIR")) s.rootIsPair = 0;
     memcpy(c->meshLo, lo, 12); memcpy(c->meshHi, hi, 12); c->orderDirty = true;
 }
 
@@ -672,6 +680,31 @@ int crt_update_scene(crt_ctx* c, const crt_scene_desc* sd, uint32_t what)
     for (uint32_t bi = 0; bi < sd->bvhCount; bi++)
         if (sd->bvhs[bi].nodesUsed != f.nodesUsed[bi] || sd->bvhs[bi].triCount != f.triCount[bi] || !sd->bvhs[bi].nodes || !sd->bvhs[bi].triangles || !sd->bvhs[bi].triangleIndices)
             return c->fail(CRT_ERR_INVALID, "crt_update_scene: BVH %u changed its topology (node / triangle count); upload the scene again", bi);
+    // ---- every check first: a refused update leaves the host mirror (and so the next successful update) untouched ----
+    if (f.kind == CRT_SCENE_TLAS && (!sd->tlasNodes || sd->tlasNodeCount != f.tlasNodeCount))
+        return c->fail(CRT_ERR_INVALID, "crt_update_scene: a two-level scene needs the node array of the TLASBVH::Build that followed the change (tlasNodes, %u nodes as uploaded)", f.tlasNodeCount);
+    if (what & CRT_UPDATE_BOUNDS) {
+        const crt::LeafTri* leaf = reinterpret_cast<const crt::LeafTri*>(f.geom.data() + f.leafOff);
+        for (uint32_t bi = 0; bi < sd->bvhCount; bi++) {
+            const crt_bvh& b = sd->bvhs[bi];
+            for (uint32_t j = 0; j < b.triCount; j++) {
+                const uint32_t ti = b.triangleIndices[j];
+                if (ti >= b.triCount) return c->fail(CRT_ERR_INVALID, "BVH %u: triangleIndices[%u] out of range", bi, j);
+                if (leaf[f.triBase[bi] + j].shadeIdx != (uint32_t)(f.triBase[bi] + ti)) return c->fail(CRT_ERR_INVALID, "BVH %u: triangleIndices changed; Refit keeps the leaf order — upload the scene again", bi);
+            }
+        }
+    }
+    uint32_t tlasHeight = 0;
+    std::vector<char> tlasImage;                                            // the TLAS sections (nodes + child pairs), flattened aside and copied in once they are known to be valid
+    if (f.kind == CRT_SCENE_TLAS) {
+        tlasImage.assign((size_t)(f.instOff - f.tlasOff), 0);
+        int r = flatten_tlas(c, sd->tlasNodes, sd->tlasNodeCount, sd->bvhCount, reinterpret_cast<crt::TlasNode*>(tlasImage.data()),
+                             reinterpret_cast<crt::NodePair*>(tlasImage.data() + (f.tlasPairOff - f.tlasOff)), &tlasHeight);
+        if (r) return r;
+        if ((c->hScene.bvhStack + tlasHeight + 1) * 64u * 4u + 15u * 256u > 64u * 1024u)
+            return c->fail(CRT_ERR_UNSUPPORTED, "TLAS height %u needs %u bytes of LDS traversal stack per wave (> 64 KiB)", tlasHeight, (c->hScene.bvhStack + tlasHeight + 1) * 256u);
+    }
+    // ---- apply ----
     size_t lo = SIZE_MAX, hi = 0;                                         // byte range of the geometry buffer to rewrite
     auto touch = [&](size_t a, size_t b) { if (a < lo) lo = a; if (b > hi) hi = b; };
     if (what & CRT_UPDATE_BOUNDS) {
@@ -685,35 +718,25 @@ int crt_update_scene(crt_ctx* c, const crt_scene_desc* sd, uint32_t what)
                 for (int k = 0; k < 2; k++) { memcpy(p.c[k].lo, b.nodes[n + k].aabbMin, 12); memcpy(p.c[k].hi, b.nodes[n + k].aabbMax, 12); }
             }
             for (uint32_t j = 0; j < b.triCount; j++) {
-                const uint32_t ti = b.triangleIndices[j];
-                if (ti >= b.triCount) return c->fail(CRT_ERR_INVALID, "BVH %u: triangleIndices[%u] out of range", bi, j);
-                const crt_tri& t = b.triangles[ti];
+                const crt_tri& t = b.triangles[b.triangleIndices[j]];
                 crt::LeafTri& lt = leaf[f.triBase[bi] + j];
-                if (lt.shadeIdx != (uint32_t)(f.triBase[bi] + ti)) return c->fail(CRT_ERR_INVALID, "BVH %u: triangleIndices changed; Refit keeps the leaf order — upload the scene again", bi);
                 for (int k = 0; k < 3; k++) { lt.v0[k] = t.vertex0[k]; lt.e1[k] = t.vertex1[k] - t.vertex0[k]; lt.e2[k] = t.vertex2[k] - t.vertex0[k]; }
             }
         }
         if (f.topCount) crt_build_treetop(pairs, (uint32_t)(f.topOff / 64), f.rootRef, reinterpret_cast<crt::NodePair*>(f.geom.data() + f.topOff), f.topCount);   // same membership, new boxes
         touch(0, (size_t)f.tlasOff);
     }
-    uint32_t tlasHeight = 0;
     if (f.kind == CRT_SCENE_TLAS) {
         if (what & CRT_UPDATE_TRANSFORMS) {
-            if (!sd->tlasNodes || sd->tlasNodeCount != f.tlasNodeCount) return c->fail(CRT_ERR_INVALID, "crt_update_scene: TLAS node count differs from the uploaded scene");
             crt::Instance* inst = reinterpret_cast<crt::Instance*>(f.geom.data() + f.instOff);
             for (uint32_t bi = 0; bi < sd->bvhCount; bi++) { memcpy(inst[bi].invT, sd->bvhs[bi].invT, 48); memcpy(inst[bi].T, sd->bvhs[bi].T, 48); }   // BLASBVH::SetTransform, blas_bvh.cpp:363-374
         }
         // TLASBVH::Build (tlas_bvh.cpp:17-55) ran on the host after SetTransform / Refit: new node array of the same size
-        if (sd->tlasNodes && sd->tlasNodeCount == f.tlasNodeCount) {
-            int r = flatten_tlas(c, sd->tlasNodes, sd->tlasNodeCount, sd->bvhCount, reinterpret_cast<crt::TlasNode*>(f.geom.data() + f.tlasOff),
-                                 reinterpret_cast<crt::NodePair*>(f.geom.data() + f.tlasPairOff), &tlasHeight);
-            if (r) return r;
-            touch((size_t)f.tlasOff, (size_t)f.shadeOff);
-            crt::Scene& s = c->hScene;
-            s.stackDepth = s.bvhStack + tlasHeight + 1;
-            c->ldsBytes = s.stackDepth * 64u * 4u;
-            if (c->ldsBytes + 15u * 256u > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "TLAS height %u needs %u bytes of LDS traversal stack per wave (> 64 KiB)", tlasHeight, c->ldsBytes);
-        }
+        memcpy(f.geom.data() + f.tlasOff, tlasImage.data(), tlasImage.size());
+        touch((size_t)f.tlasOff, (size_t)f.shadeOff);
+        crt::Scene& s = c->hScene;
+        s.stackDepth = s.bvhStack + tlasHeight + 1;
+        c->ldsBytes = s.stackDepth * 64u * 4u;
     }
     if (lo >= hi) return CRT_OK;
     // In-place rewrite, no allocation of device memory and no host wait for the GPU: the copy runs on the main stream, which is ordered behind every
@@ -842,10 +865,10 @@ static uint32_t block_desc(uint32_t tile, uint32_t laneBase, uint32_t lanes, uin
 static uint32_t split_by_width(std::vector<uint32_t>& table)
 {
     uint32_t maxNarrow = 0u;
-    if (const char* e = getenv("CRT_NARROW_LANES")) maxNarrow = std::min<uint32_t>((uint32_t)atoi(e), crt_narrow_max_lanes());
+    if (const char* e = hook("CRT_NARROW_LANES")) maxNarrow = std::min<uint32_t>((uint32_t)atoi(e), crt_narrow_max_lanes());
     if (maxNarrow == 0u) return (uint32_t)table.size();
     uint32_t limit = 3072u;                                        // 256 CUs x 12 wavefronts: all narrow blocks in flight at once, else the launch is bound by machine time
-    if (const char* e = getenv("CRT_NARROW_LIMIT")) limit = (uint32_t)atoi(e);
+    if (const char* e = hook("CRT_NARROW_LIMIT")) limit = (uint32_t)atoi(e);
     std::vector<uint32_t> wide, narrow; wide.reserve(table.size()); narrow.reserve(table.size());
     for (uint32_t d : table) { if ((1u << ((d >> 22) & 7u)) <= maxNarrow) narrow.push_back(d); else wide.push_back(d); }
     if (narrow.size() > limit) return (uint32_t)table.size();
@@ -886,7 +909,7 @@ static int upload_block_table(crt_ctx* c, const std::vector<uint8_t>& lanes, con
     }
     if (table.size() > 0x7fffffffull) return c->fail(CRT_ERR_INVALID, "block table too large");
     c->nBlocksWide = split_by_width(table);
-    if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] latency table: %zu wavefronts for %u tiles (slowest tile of the base stage %.2f ms)\n", table.size(), n, n ? cost[order[0]] * 1e-5 : 0.0);
+    if (hook("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] latency table: %zu wavefronts for %u tiles (slowest tile of the base stage %.2f ms)\n", table.size(), n, n ? cost[order[0]] * 1e-5 : 0.0);
     if (c->descCap < table.size()) {
         if (c->dBlockDesc) (void)hipFree(c->dBlockDesc);
         if (c->hBlockDesc) (void)hipHostFree(c->hBlockDesc);
@@ -916,7 +939,7 @@ static int next_block_table(crt_ctx* c)
     if (c->tuneCount[s] && (c->latBest == s || !c->tuneCount[c->latBest] || c->tuneMs[s] < c->tuneMs[c->latBest])) c->latBest = s;
     bool last = s >= K;
     std::vector<std::pair<double, uint32_t>> steps;
-    if (const char* e = getenv("CRT_LAT_POLICY")) {
+    if (const char* e = hook("CRT_LAT_POLICY")) {
         for (const char* p = e; *p;) {
             char* q = nullptr; const double sh = strtod(p, &q); if (q == p || *q != ':') break;
             const long L = strtol(q + 1, &q, 10); if (L < 1 || L > 64 || (64 % L) != 0) break;
@@ -933,8 +956,8 @@ static int next_block_table(crt_ctx* c)
     auto finish = [&]() -> int {
         c->latDone = true; c->latConfirming = false;
         const int b = fastest(-1); c->latBest = b < 0 ? 0 : b;
-        if (getenv("CRT_LAT_FORCE")) c->latBest = s;                       // diagnostics: keep the last table whatever its time
-        if (getenv("CRT_LAT_VERBOSE")) { fprintf(stderr, "[crt] latency stages:"); for (int k = 0; k <= K; k++) if (c->tuneCount[k]) fprintf(stderr, " %d: %.2f ms", k, c->tuneMs[k]); fprintf(stderr, " -> %d\n", c->latBest); }
+        if (hook("CRT_LAT_FORCE")) c->latBest = s;                       // diagnostics: keep the last table whatever its time
+        if (hook("CRT_LAT_VERBOSE")) { fprintf(stderr, "[crt] latency stages:"); for (int k = 0; k <= K; k++) if (c->tuneCount[k]) fprintf(stderr, " %d: %.2f ms", k, c->tuneMs[k]); fprintf(stderr, " -> %d\n", c->latBest); }
         return install(c->latBest);
     };
     if (c->latConfirming) {                                               // a confirmation launch of stage s has been timed (harvest_tuning keeps each stage's minimum)
@@ -945,7 +968,7 @@ static int next_block_table(crt_ctx* c)
     if (last) {
         // every stage has ONE timing so far, and launch durations scatter by a few per cent: the two fastest stages run once more before the choice is final
         const int a = fastest(-1), b2 = fastest(a);
-        if (getenv("CRT_LAT_FORCE") || a < 0 || b2 < 0) return finish();
+        if (hook("CRT_LAT_FORCE") || a < 0 || b2 < 0) return finish();
         c->latQueue = {a, b2}; c->latConfirming = true;
         return install(a);
     }
@@ -958,7 +981,7 @@ static int next_block_table(crt_ctx* c)
             for (const auto& st : steps) if (top > 0 && (double)baseC[i] >= st.first * (double)top) { L[i] = (uint8_t)st.second; break; }
     } else {
         double aim = (s == 0 && !c->latProbed) ? 0.64 : 0.92;               // (a probed stage 0 is a narrowed table already: refine, do not halve again)
-        if (const char* e = getenv("CRT_LAT_AIM")) { const double v = atof(e); if (s > 0 && v > 0) aim = v; }
+        if (const char* e = hook("CRT_LAT_AIM")) { const double v = atof(e); if (s > 0 && v > 0) aim = v; }
         for (uint32_t i = 0; i < n; i++) L[i] = next_lanes(baseL[i], baseC[i], aim * (double)top);
     }
     const int r = upload_block_table(c, L, baseC);
@@ -1097,7 +1120,7 @@ static int adopt_job_costs(crt_ctx* c)
         const double drain = (double)clk[2] / (double)(c->recResident ? c->recResident : 1u);
         c->poolWindowTicks = 0;
         if (c->recWindows && (double)c->recWaves >= 1.5 * (double)c->recResident && s0 > 0) c->poolWindowTicks = (s0 + drain) / (double)c->recWindows / (c->recPool ? 1.0 : 1.2);
-        if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] measured %u windows with %s: %u wavefronts, last one started %.2f ms after the first, then %.2f ms of drain -> %.3f ms of machine time per window under the pool\n", c->recWindows, c->recPool ? "the pool" : "one stream per lane", c->recWaves, s0 * 1e-5, drain * 1e-5, c->poolWindowTicks * 1e-5);
+        if (hook("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] measured %u windows with %s: %u wavefronts, last one started %.2f ms after the first, then %.2f ms of drain -> %.3f ms of machine time per window under the pool\n", c->recWindows, c->recPool ? "the pool" : "one stream per lane", c->recWaves, s0 * 1e-5, drain * 1e-5, c->poolWindowTicks * 1e-5);
     }
     c->jobOrder.resize(n);
     for (uint32_t i = 0; i < n; i++) c->jobOrder[i] = i;
@@ -1120,9 +1143,9 @@ static void plan_job(const crt_ctx* c, uint32_t windows, uint32_t frames, bool p
 {
     table.clear(); *head = 0;
     const uint32_t n = c->tileCount;
-    if (!c->jobCostValid || windows < 2u || windows > 64u || n > 0x10000u || c->cfg.collectStats || getenv("CRT_SPLIT_OFF")) return;
+    if (!c->jobCostValid || windows < 2u || windows > 64u || n > 0x10000u || c->cfg.collectStats || hook("CRT_SPLIT_OFF")) return;
     if (pool && c->streams.size() < 2) return;
-    if (const char* e = getenv("CRT_SPLIT_FORCE")) {                      // tests: the first h tiles through the table, alternating wavefront widths
+    if (const char* e = hook("CRT_SPLIT_FORCE")) {                      // tests: the first h tiles through the table, alternating wavefront widths
         const uint32_t h = std::min<uint32_t>((uint32_t)atoi(e), pool ? n - 1u : n);
         static const uint32_t Ls[4] = {64u, 16u, 2u, 1u};
         for (uint32_t r = 0; r < (pool ? h : n); r++) { const uint32_t L = r < h ? Ls[r & 3u] : 64u; for (uint32_t w = 0; w < windows; w++) for (uint32_t b0 = 0; b0 < 64u; b0 += L) table.push_back(block_desc(c->jobOrder[r], b0, L, w)); }
@@ -1131,7 +1154,7 @@ static void plan_job(const crt_ctx* c, uint32_t windows, uint32_t frames, bool p
     // cost unit: a pool wavefront's duration per 64 streams while the costs were measured (render_pool_kernel).  In a saturated job the wavefronts of the most expensive
     // tiles run 1.2x longer than that (82 ms against 68 ms on the bunny); one-stream-per-lane wavefronts need 1.2x the machine time of the pool's.
     double poolLong = 2.4, wideLoad = 1.1, poolSlots = 4096.0, wideMt = 1.2, narrowSlots = 3500.0;
-    if (const char* e = getenv("CRT_PLAN_NARROW_SLOTS")) narrowSlots = atof(e);
+    if (const char* e = hook("CRT_PLAN_NARROW_SLOTS")) narrowSlots = atof(e);
     const double K = (double)windows;
     // machine time of one window's pool wavefront of a tile, per unit of its cost: from the measured machine time per window when the measuring launch
     // oversubscribed the chip (adopt_job_costs), else from the wavefront durations (which then ran without much competition)
@@ -1157,7 +1180,7 @@ static void plan_job(const crt_ctx* c, uint32_t windows, uint32_t frames, bool p
         if (cls >= 2) { lanes[r] = (uint8_t)kLatLanes[cls - 2]; narrow++; }
     }
     if (pool && h >= n) h = n - 1u;
-    if (getenv("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] job of %u windows, %u tiles: makespan aim %.1f ms (most expensive tile %.2f ms); %u tiles to the block table, %u of them narrow, %s\n", windows, n, T * 1e-5, top * 1e-5, pool ? h : (narrow ? n : 0u), narrow, pool ? "rest to the pool" : "no pool");
+    if (hook("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] job of %u windows, %u tiles: makespan aim %.1f ms (most expensive tile %.2f ms); %u tiles to the block table, %u of them narrow, %s\n", windows, n, T * 1e-5, top * 1e-5, pool ? h : (narrow ? n : 0u), narrow, pool ? "rest to the pool" : "no pool");
     if (pool ? h == 0u : narrow == 0u) return;
     const uint32_t upto = pool ? h : n;
     for (uint32_t r = 0; r < upto; r++) {
@@ -1218,7 +1241,7 @@ static int probe_tile_costs(crt_ctx* c, hipStream_t st)
     { std::vector<uint32_t> sorted(est); const size_t k = (size_t)((double)n * 0.98); std::nth_element(sorted.begin(), sorted.begin() + std::min<size_t>(k, n - 1), sorted.end()); top = sorted[std::min<size_t>(k, n - 1)]; }
     std::vector<uint8_t>& L = c->latL[0]; L.assign(n, 64);
     double aim = 0.90;
-    if (const char* e = getenv("CRT_LAT_PROBE_AIM")) aim = atof(e);
+    if (const char* e = hook("CRT_LAT_PROBE_AIM")) aim = atof(e);
     if (top > 0) for (uint32_t i = 0; i < n; i++) L[i] = next_lanes(64, est[i], aim * (double)top);
     c->latProbed = true;
     bool any = false; for (uint32_t i = 0; i < n; i++) any = any || L[i] != 64;
@@ -1257,17 +1280,20 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         harvest_tuning(c);
         fold_completed(c, c->evRender, &c->foldedRenderMs, &c->foldedLaunches); fold_completed(c, c->evAcc, &c->foldedAccMs, nullptr);
         if ((r = take_event(c, c->evRender, &ev))) return r;
+        // the pair is in the timing list from here on; any error exit before its end event is recorded takes it back (a half-recorded pair would make every
+        // later crt_get_timing fail in hipEventElapsedTime)
+        struct PairGuard { crt_ctx* c; bool armed; ~PairGuard() { if (armed && !c->evRender.empty()) { c->evPool.push_back(c->evRender.back()); c->evRender.pop_back(); } } } pairGuard{c, true};
         // latency mode of a single-window launch (render_tiles_kernel): one wavefront per tile, or the current block table (see next_block_table)
         const uint32_t* blockDesc = nullptr; uint32_t nBlocks = 0; bool wantCost = false;
         // ... only when the GPU is idle at submission: a caller that queues launch after launch wants throughput, and narrow wavefronts buy latency with issue
         // slots (56 queued single-window calls: 6.4 ms each with one wave per tile, 12.4 ms with the tuned table)
         const bool gpuIdle = !c->lastRenderEnd || hipEventQuery(c->lastRenderEnd) == hipSuccess;
-        if (nf <= 64u && nf >= 8u && gpuIdle && !c->cfg.collectStats && c->tileCount <= 0x10000u && !getenv("CRT_LAT_OFF")) {
+        if (nf <= 64u && nf >= 8u && gpuIdle && !c->cfg.collectStats && c->tileCount <= 0x10000u && !hook("CRT_LAT_OFF")) {
             if (c->costPending && hipEventQuery(c->costCopied) == hipSuccess) { c->costPending = false; harvest_tuning(c); if ((r = next_block_table(c))) return r; }
-            if (c->latStage == 0 && !c->latProbed && !c->latWarm && !c->costPending && nf == 64u && !getenv("CRT_LAT_POLICY") && !getenv("CRT_LAT_NO_PROBE")) { if ((r = probe_tile_costs(c, st))) return r; }
+            if (c->latStage == 0 && !c->latProbed && !c->latWarm && !c->costPending && nf == 64u && !hook("CRT_LAT_POLICY") && !hook("CRT_LAT_NO_PROBE")) { if ((r = probe_tile_costs(c, st))) return r; }
             const int stage = c->latStage;
             if (stage || c->latProbed) { blockDesc = c->dBlockDesc; nBlocks = c->nBlocks; HIPCK(c, hipStreamWaitEvent(st, c->descReady, 0)); }
-            wantCost = (!c->latDone && !c->costPending) || (c->latDone && getenv("CRT_LAT_RECORD"));      // (the latter: diagnostics, crt_debug_tile_costs)
+            wantCost = (!c->latDone && !c->costPending) || (c->latDone && hook("CRT_LAT_RECORD"));      // (the latter: diagnostics, crt_debug_tile_costs)
             c->evRender.back().mode = c->latDone ? -1 : stage;
             if (wantCost && !c->latDone) c->costStage = stage;
         }
@@ -1305,7 +1331,7 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         const uint64_t minWaves = c->poolMinWaves != 65000u ? c->poolMinWaves : (c->jobCostValid ? 43000u : 65000u);
         const bool pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * ((nf + 63u) / 64u) >= minWaves && (c->poolMinWaves == 0 || nf > 64u);
         hipError_t le;
-        if (getenv("CRT_DEBUG_FAIL_LAUNCH")) le = hipErrorInvalidConfiguration;       // tests: the runtime refuses the launch
+        if (hook("CRT_DEBUG_FAIL_LAUNCH")) le = hipErrorInvalidConfiguration;       // tests: the runtime refuses the launch
         else {
             const uint32_t windows = (nf + 63u) / 64u;
             uint32_t head = 0, jobBlocks = 0;
@@ -1370,13 +1396,13 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
             if (jobBlocks && le == hipSuccess) c->splitLaunches++;
         }
         if (le != hipSuccess) {
-            // a launch that failed has rendered nothing: take its timing pair back (a half-recorded pair would poison crt_get_timing), leave the accumulator
-            // and the region bookkeeping untouched — the frames before it are in, this one and the rest are not — and report
-            c->evPool.push_back(c->evRender.back()); c->evRender.pop_back();
+            // a launch that failed has rendered nothing: its timing pair goes back (pairGuard), the accumulator and the region bookkeeping stay untouched —
+            // the frames before it are in, this one and the rest are not — and the error is reported
             return c->hip(le, pool ? "launch of render_pool_kernel" : "launch of render_tiles_kernel");
         }
         if (pool) c->poolLaunches++;
         HIPCK(c, hipEventRecord(ev.b, st));
+        pairGuard.armed = false;
         c->lastRenderEnd = ev.b;
         if (wantJobCost) {
             HIPCK(c, hipMemcpyAsync(c->hJobCost, c->dJobCost, job_cost_bytes(c), hipMemcpyDeviceToHost, st));

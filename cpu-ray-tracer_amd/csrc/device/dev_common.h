@@ -169,14 +169,6 @@ __device__ __forceinline__ float rnd_pm1(uint32_t& s)
 
 
 struct Hit { float t, u, v; int objIdx, triIdx; };
-#ifdef CRT_DUP
-// diagnostic build (-DCRT_DUP=n): region n of the SHADE phase is evaluated a second time on laundered copies of its inputs and the
-// result is kept alive, so the difference in SQ_INSTS_VALU against the normal build is that region's dynamic cost.  Never shipped.
-__device__ __forceinline__ float lnd(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ f3 lnd3(f3 v) { return mk3(lnd(v.x), lnd(v.y), lnd(v.z)); }
-__device__ __forceinline__ void sink(float x) { asm volatile("" :: "v"(x)); }
-__device__ __forceinline__ void sink3(f3 v) { sink(v.x); sink(v.y); sink(v.z); }
-#endif
 struct Cnt { uint32_t rays, primary, interior, leaf, tri, tlas, visits, meshhits; };
 
 typedef float rec4 __attribute__((ext_vector_type(4)));     // a fetched 16-byte piece of a record (native vector: usable as an asm operand)

@@ -200,9 +200,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
             if (miss) {                                                           // GetSkyColor, file_scene.cpp:142-154
                 const float phi = crt_atan2f(-D.z, D.x) + CRT_PI, theta = crt_acosf(-D.y);
                 tu = phi * CRT_INV2PI; tv = theta * CRT_INVPI;
-#if defined(CRT_DUP) && CRT_DUP == 1
-                { const f3 d2 = lnd3(D); sink(crt_atan2f(-d2.z, d2.x) + CRT_PI); sink(crt_acosf(-d2.y)); }
-#endif
             }
             if (surf) {
                 I = O + h.t * D;
@@ -243,13 +240,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
             // stage 3: the one texel fetch (Texture::Sample) — sky colour of a miss, albedo of a textured surface
             f3 c = mk3(1.0f, 1.0f, 1.0f);
             if (miss || (surf && tW > 0)) c = tex_sample(sc, tOff, tW, tH, tu, tv);
-#if defined(CRT_DUP) && CRT_DUP == 2
-            if (miss || (surf && tW > 0)) sink3(tex_sample(sc, tOff, tW, tH, lnd(tu), lnd(tv)));
-#endif
-#if defined(CRT_DUP) && CRT_DUP == 10
-            if (surf && h.objIdx >= 2) { const float w = 1 - lnd(h.u) - h.v; const f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q0.w, q1.x, q1.y), n2 = mk3(q1.z, q1.w, q2.x);
-                sink3(normalize3(w * n0 + h.u * n1 + h.v * n2)); sink(w * q2.y + h.u * q2.w + h.v * q3.y); sink(w * q2.z + h.u * q3.x + h.v * q3.z); }
-#endif
             // stage 4a: the bounce (renderer.cpp:76-99).  `v` = outgoing direction (a diffuse one still to be normalised), `pre` = the
             // throughput factor without the cosine term of the diffuse branch
             f3 v = O, pre = O; bool norm = false, diffuse = false, newInside = false;
@@ -283,9 +273,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                         const float rx = rnd_pm1(seed);
                         Rr = mk3(rx, ry, rz);
                     } while (dot3(Rr, Rr) > 1);
-#if defined(CRT_DUP) && CRT_DUP == 7
-                    { uint32_t s2 = seed ^ 0x9e3779b9u; f3 R2; do { const float rz = rnd(s2) * 2 - 1, ry = rnd(s2) * 2 - 1, rx = rnd(s2) * 2 - 1; R2 = mk3(rx, ry, rz); } while (dot3(R2, R2) > 1); sink3(R2); }
-#endif
                     if (dot3(Rr, N) < 0) Rr = Rr * -1.0f;
                     v = Rr; norm = true; diffuse = true;
                     const f3 brdf = c * CRT_INVPI;
@@ -301,9 +288,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
 #pragma unroll
                 for (int k = 4; k >= 0; k--)
                     if (depth > k) L = mk3(fst[(3 * k) * 64], fst[(3 * k + 1) * 64], fst[(3 * k + 2) * 64]) * L;
-#if defined(CRT_DUP) && CRT_DUP == 8
-                { f3 L2 = lnd3(c); for (int k = 4; k >= 0; k--) if (depth > k) L2 = mk3(fst[(3 * k) * 64], fst[(3 * k + 1) * 64], fst[(3 * k + 2) * 64]) * L2; sink3(L2); }
-#endif
                 uint32_t pix = item, pass = 0;
                 if (passes != 1u) { pix = item / passes; pass = item - pix * passes; }
                 slab[((size_t)tl * 256u + pix) * (64u * passes) + ((laneBase + lane) * passes + pass)] = make_float4(L.x, L.y, L.z, 0.0f);
@@ -320,9 +304,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                 const float u = ((float)x + jx) * cam[12], vv = ((float)y + jy) * cam[13];
                 const f3 P = TL + u * (TR - TL) + vv * (BL - TL);
                 v = P - camPos; norm = true;
-#if defined(CRT_DUP) && CRT_DUP == 9
-                { uint32_t s2 = seed; const float jy2 = rnd(s2), jx2 = rnd(s2); const float u2 = ((float)x + jx2) * sc.invW, v2 = ((float)y + jy2) * sc.invH; sink3(TL + u2 * (TR - TL) + v2 * (BL - TL) - camPos); }
-#endif
                 inside = false; depth = 0; fresh = false;
                 cn.primary++;
             }
@@ -330,9 +311,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
             if (live) {
                 const float inv = rcp_exact(__builtin_sqrtf(dot3(v, v)));         // normalize(): v * (1 / sqrtf(dot(v, v)))
                 const f3 nv = norm ? v * inv : v;
-#if defined(CRT_DUP) && CRT_DUP == 5
-                { const f3 v2 = lnd3(v); sink3(v2 * (1.0f / __builtin_sqrtf(dot3(v2, v2)))); }
-#endif
                 if (surf) {
                     const f3 factor = diffuse ? pre * dot3(nv, N) : pre;
                     float* fd = fst + depth * 192;                                // depth <= 4 here: a surface hit at depth >= depthLimit (<= 5) ended the path
@@ -341,9 +319,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                     O = I + nv * CRT_EPS; inside = newInside;
                 } else O = camPos;
                 D = nv; rD = rcp_exact3(nv);
-#if defined(CRT_DUP) && CRT_DUP == 4
-                { const f3 n2 = lnd3(nv); sink3(mk3(1 / n2.x, 1 / n2.y, 1 / n2.z)); }
-#endif
                 cn.rays++;
                 h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
                 {
@@ -356,9 +331,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                     lf.lightAxis = asu(ax[0]); lf.floorAxisY = asu(ax[1]);
                     hit_light_floor(lf, O, D, h);
                 }
-#if defined(CRT_DUP) && CRT_DUP == 3
-                { Hit h2; h2.t = 1e34f; h2.u = 0; h2.v = 0; h2.objIdx = -1; h2.triIdx = -1; hit_light_floor(sc, lnd3(O), lnd3(D), h2); sink(h2.t); sink((float)h2.objIdx); }
-#endif
                 tO = O; tD = D; trD = rD; rayFinite = finite3(rD);
                 sp = 0;
                 if (sc.rootIsPair) {
@@ -371,9 +343,6 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                     float d1, d2;
                     if (__builtin_amdgcn_ballot_w64(!rayFinite) == 0ull) { d1 = box_fast(a0, a1, O, rD, h.t); d2 = box_fast(b0, b1, O, rD, h.t); }
                     else { d1 = box_exact(a0, a1, O, rD, h.t); d2 = box_exact(b0, b1, O, rD, h.t); }
-#if defined(CRT_DUP) && CRT_DUP == 6
-                    { const f3 o2 = lnd3(O), r2 = lnd3(rD); sink(box_fast(a0, a1, o2, r2, h.t)); sink(box_fast(b0, b1, o2, r2, h.t)); }
-#endif
                     const bool sw = d1 > d2;
                     const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
                     const uint32_t rn = sw ? asu(b0.w) : asu(a0.w), rf = sw ? asu(a0.w) : asu(b0.w);

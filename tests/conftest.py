@@ -11,6 +11,7 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASSETS = os.path.join(REPO, "assets")
 GOLDEN = os.path.join(REPO, "tests", "golden")
+os.environ["CRT_ENABLE_DEBUG_HOOKS"] = "1"      # the tests steer the library through its diagnostic environment switches (dead in a process that does not opt in)
 sys.path.insert(0, os.path.join(REPO, "oracle"))
 sys.path.insert(0, REPO)
 

@@ -104,3 +104,42 @@ def test_update_is_cheap_and_rejects_topology_changes(crt):
     c2 = crt.Context(64, 64); fs.upload(c2)
     with pytest.raises(crt.CrtError):
         fs.update(c2, crt.UPDATE_TRANSFORMS)                           # a FileScene bakes its transforms into the triangles
+
+
+def test_refused_updates_leave_the_scene_intact(crt, orc):
+    """a two-level update without the rebuilt TLAS (tlasNodes NULL / wrong count) is CRT_ERR_INVALID for every `what` — not a stale TLAS or a crash —
+    and a refused update (permuted triangleIndices) does not touch the host mirror: the next valid update still gives the oracle's image"""
+    W, H = 96, 64
+    tex = np.full((4, 4), 0x808080, np.uint32)
+    ident = np.eye(4, dtype=np.float32)
+    # two-level scene, description passed straight through the C ABI
+    hs = crt.HostScene(scene_path("tlas_scene.xml"), 1, ASSETS)
+    ctx = crt.Context(W, H); hs.upload(ctx); ctx.render(1, 1, 1); ctx.sync()
+    bvhs = []
+    for i in range(hs.bvh_count()):
+        b = hs.bvh(i); T, invT, _, _ = hs.blas_transform(i)
+        b.update(objIdx=i + 2, matIdx=0, T=T, invT=invT); bvhs.append(b)
+    nodes, used = hs.tlas()
+    common = dict(textures=[tex, tex], floor_texture=0, sky_texture=1, materials=[(0.0, 0.0, (0.0, 0.0, 0.0), -1)], light_T=ident, light_invT=ident)
+    for what in (crt.UPDATE_BOUNDS, crt.UPDATE_TRANSFORMS, crt.UPDATE_BOUNDS | crt.UPDATE_TRANSFORMS):
+        with pytest.raises(crt.CrtError):
+            ctx.upload_desc(crt.SCENE_TLAS, bvhs, tlas_nodes=None, update_what=what, **common)
+        with pytest.raises(crt.CrtError):
+            ctx.upload_desc(crt.SCENE_TLAS, bvhs, tlas_nodes=nodes[:used - 1], update_what=what, **common)
+    ctx.upload_desc(crt.SCENE_TLAS, bvhs, tlas_nodes=nodes[:used], update_what=crt.UPDATE_BOUNDS | crt.UPDATE_TRANSFORMS, **common)      # the complete description is accepted
+    ctx.clear(); ctx.render(1, 2, 1)
+    o, _ = orc.load_scene(scene_path("tlas_scene.xml"), 1, ASSETS); o.renderer_init(W, H); o.render(2, 2)
+    assert np.array_equal(ctx.accumulator(), o.accumulator())
+    # single-level scene: a permuted leaf order is refused, the mirror is untouched, the next refit is still exact
+    from test_oracle_pinning import deform
+    fs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    c2 = crt.Context(W, H); fs.upload(c2); c2.render(1, 1, 1); c2.sync()
+    b = fs.bvh(0); bad = dict(b); bad["triIndices"] = b["triIndices"][::-1].copy()
+    with pytest.raises(crt.CrtError):
+        c2.upload_desc(crt.SCENE_FILE, [bad], obj_mat_idx=[0], update_what=crt.UPDATE_BOUNDS, **common)
+    t = b["tris"]; moved = deform(np.stack([t["vertex0"], t["vertex1"], t["vertex2"]], axis=1))
+    o2, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS); o2.renderer_init(W, H)
+    fs.move_and_refit(0, moved); o2.move_and_refit(0, moved)
+    fs.update(c2, crt.UPDATE_BOUNDS)
+    c2.clear(); c2.render(1, 2, 1); o2.render(2, 2)
+    assert np.array_equal(c2.accumulator(), o2.accumulator())

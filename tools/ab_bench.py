@@ -3,6 +3,7 @@
 (in the authoring container: `python tools/ab_bench.py build NAME=-DFOO=1 ...`), and times them on the GPU box
 (`python tools/ab_bench.py run`), each variant in its own process, median of the render kernel's HIP-event time."""
 import json, os, subprocess, sys
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(REPO, "build", "variants")
 PKG = os.path.join(REPO, "cpu-ray-tracer_amd")

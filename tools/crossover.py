@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: job time of render_tiles_kernel vs render_pool_kernel for jobs of 2..64 windows (where should the back end switch?)."""
 import importlib.util, os, sys, time
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))
 crt = importlib.util.module_from_spec(spec); spec.loader.exec_module(crt)

@@ -3,6 +3,7 @@
 4-window job (every variant must print the same one: scheduling never changes a pixel).
     python tools/k_bench.py [scene.xml kind [W H [K1 K2]]]        env: KB_ONLY=name1,name2 restricts the variants"""
 import os, subprocess, sys
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 V = os.path.join(REPO, "build", "variants")
 child = r'''

@@ -2,6 +2,7 @@
 """Does splitting a job into several concurrent launches (crt_config.maxFramesPerLaunch) let the ordered accumulate of the early launches overlap the later ones?
 (No: equal-priority launches share the machine and end together — 2 x 32 windows 221.2 ms like 1 x 64, smaller pieces are slower.)  Bit-checked by CRC."""
 import importlib.util, os, sys, time, zlib
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 import numpy as np
 REPO = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))

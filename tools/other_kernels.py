@@ -2,6 +2,7 @@
 """Workload for profiling the kernels bench.py does not exercise (run under rocprofv3 by tools/profile_other_kernels.sh):
 whitted_kernel (config 1: cube, 640x360), find_nearest_kernel (1 M rays, bunny and TLAS scene), find_nearest_kd_kernel / find_nearest_grid_kernel."""
 import importlib.util, os, sys, time
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))

@@ -3,6 +3,7 @@
 its 64 lanes, for one pool-only job (default 32 windows of the bunny scene at 1280x720).  Prints one JSON line.
     python tools/pool_density.py [scene.xml kind [windows [W H]]]"""
 import ctypes as C, importlib.util, json, os, sys, time
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 os.environ.setdefault("CRT_RENDER_KERNEL", "pool_always")
 os.environ.setdefault("CRT_SPLIT_OFF", "1")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

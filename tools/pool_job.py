@@ -2,6 +2,7 @@
 """One pool-only job of K windows (default 32) of a scene, twice (warm-up + timed); prints a JSON line with the timed job's duration and ray counter.
 The program the PMC passes of tools/variant_pmc.sh profile.   python3 tools/pool_job.py [K scene.xml kind W H]"""
 import importlib.util, json, os, sys, time
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 os.environ.setdefault("CRT_RENDER_KERNEL", "pool_always"); os.environ.setdefault("CRT_SPLIT_OFF", "1")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))

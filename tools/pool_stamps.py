@@ -2,6 +2,7 @@
 """Diagnostic (-DCRT_POOL_STAMPS build, CRT_LIB_PATH=...): share of render_pool_kernel's wave time per section of its loop, one pool-only job.
     python tools/pool_stamps.py [scene.xml kind [windows [W H]]]"""
 import ctypes as C, importlib.util, json, os, sys
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 os.environ.setdefault("CRT_RENDER_KERNEL", "pool_always"); os.environ.setdefault("CRT_SPLIT_OFF", "1")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))

@@ -2,6 +2,7 @@
 """Diagnostic (-DCRT_POOL_TIMELINE build, CRT_LIB_PATH=...): wavefronts of render_pool_kernel in flight over time for a K-window job, and what the job's
 tail looks like.  Usage: python tools/pool_timeline.py [K] [scene.xml kind]"""
 import ctypes as C, importlib.util, os, sys
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: render the same job with render_pool_kernel and render_tiles_kernel and compare the accumulators bit for bit."""
 import importlib.util, os, sys
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))

@@ -2,6 +2,7 @@
 """Single-render latency (clear, crt_render(1, 64, 1), sync) over the tuner's whole sequence: first render, untuned, every stage, settled median.
     python tools/single_render.py [scene.xml kind W H [renders]]"""
 import importlib.util, json, os, sys, time
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))

@@ -2,6 +2,7 @@
 """Job time (one crt_render of K windows, 64 spp each) with and without split launches (CRT_SPLIT_OFF / CRT_SPLIT_SLACK) and with either kernel forced, bit-checked
 against each other.  Usage: python tools/split_probe.py [K,K,..] [scene.xml kind W H]"""
 import importlib.util, os, subprocess, sys, time
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 child = r'''
 import importlib.util, os, sys, time, zlib

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (-DCRT_STAMPS build, CRT_LIB_PATH=...): dumps the per-tile clocks / phase stamps of one 64-frame window to an .npz."""
 import ctypes as C, importlib.util, os, sys
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))

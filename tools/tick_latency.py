@@ -1,4 +1,5 @@
 import importlib.util, os, sys, time, numpy as np
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 REPO = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))
 crt = importlib.util.module_from_spec(spec); spec.loader.exec_module(crt)

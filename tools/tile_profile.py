@@ -2,6 +2,7 @@
 """Per-tile wall-time map of render_tiles_kernel (collectStats context): shows load imbalance between tiles and the
 dispatch timeline.  Usage: python tools/tile_profile.py [scene.xml kind W H spp]"""
 import importlib.util, os, sys
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))

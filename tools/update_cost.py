@@ -2,6 +2,7 @@
 """Cost of one animation step behind the boundary (SURVEY 8(f)3): BLASBVH::SetTransform + TLASBVH::Build on the host, crt_update_scene
 (in-place rewrite of the TLAS / instance sections), one Tick.  Usage: python tools/update_cost.py [scene.xml W H]"""
 import importlib.util, os, sys, time
+os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads its diagnostic environment switches only for processes that opt in
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("cpu_ray_tracer_amd", os.path.join(REPO, "cpu-ray-tracer_amd", "__init__.py"))
