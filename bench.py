@@ -39,7 +39,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 REPO = os.path.dirname(os.path.abspath(__file__))
 ASSETS = os.path.join(REPO, "assets")
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
-VALU_ISSUE_PEAK_GINSTR = 1050.0   # measured fp32 VALU issue peak of the chip, G wave-instructions/s (tools/microbench/valu_peak.hip, profiles/r01_valu_peak.txt)
+VALU_ISSUE_PEAK_GINSTR = 1050.0   # measured fp32 VALU issue peak of the chip, G wave-instructions/s (tools/microbench/valu_peak.hip, profiles/r03_valu_peak.txt)
+VALU_ISSUE_PEAK_THEORETICAL = 1229.0   # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 fp32 instruction (MI355X_MICROARCH.md)
+VALU_INT_PEAK_GINSTR = 605.0      # measured rate of integer / compare VALU instructions (v_lshl, v_xor, v_cmp + v_cndmask pairs): half the fp32 rate (same microbench)
 
 
 def load_crt():
@@ -279,21 +281,34 @@ def main():
     alg_bytes_launch = algorithmic_bytes(counts) * (args.steps + (args.warmup if warm_same else 0)) / max(all_launches, 1)
     achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     job_launch_ms = kernel_ms / max(launches, 1)
-    # HBM bytes and VALU wave-instructions of the render kernel from the PMC passes (tools/collect_profiles.sh -> profiles/hbm_traffic.json),
-    # stored PER 64-FRAME WINDOW of the job's launch and scaled to this run's launch; only for the workload they were collected on
-    traffic = valu_instrs = pmc = None
+    # HBM bytes and VALU wave-instructions of the timed job's render kernels (render_pool_kernel and, in a split job, the block-table render_tiles_kernel beside it)
+    # from rocprofv3 PMC passes of THIS command (tools/profile_job.sh -> profiles/job_counters.json, keyed by job shape); a shape that has not been profiled
+    # falls back to the per-window figures of the 64-window pool-only job (profiles/hbm_traffic.json) and says so in counters_from
+    job_shape = "%s|%d|%dx%d|spp%d|steps%d|warmup%d|gpus%d" % (args.scene, args.kind, W, H, SPP, args.steps, args.warmup, world)
+    traffic = valu_instrs = lane_util = l2_hit = None
+    counters_from = None
     windows_per_launch = (1 / launches_per_step) if launches_per_step else 0
-    pmc_path = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if os.path.exists(pmc_path):
+    try:
+        jc = json.load(open(os.path.join(REPO, "profiles", "job_counters.json"))).get(job_shape)
+    except Exception:
+        jc = None
+    if jc and "fetch_bytes_raw" in jc and "valu_wave_instructions" in jc:
+        traffic = int((jc["fetch_bytes_raw"] + jc["write_bytes"]) / max(launches, 1))
+        valu_instrs = int(jc["valu_wave_instructions"] / max(launches, 1))
+        lane_util = jc.get("lane_utilisation"); l2_hit = jc.get("l2_hit_rate")
+        counters_from = "%s: rocprofv3 PMC passes of this exact command (job shape %s), every render kernel of the timed job" % (jc.get("file", "profiles/job_counters.json"), job_shape)
+    else:
+        pmc_path = os.path.join(REPO, "profiles", "hbm_traffic.json")
         try:
             t = json.load(open(pmc_path))
             if t.get("workload") == [args.scene, args.kind, W, H, SPP] and world == 1 and job_kernel in t.get("kernel", ""):
-                pmc = t
                 pw = t["per_window"]
                 traffic = int((pw["fetch_bytes_raw"] + pw["write_bytes"]) * windows_per_launch)
                 valu_instrs = int(pw["valu_wave_instructions"] * windows_per_launch)
+                lane_util = t.get("lane_utilisation"); l2_hit = t.get("l2_hit_rate")
+                counters_from = "profiles/hbm_traffic.json: PMC of the 64-window pool-only job, per window x %.1f windows of this launch (this job shape has not been profiled: a model, not a counter)" % windows_per_launch
         except Exception:
-            traffic = valu_instrs = pmc = None
+            pass
     single_ms = sorted(lat[-5:])[2] if lat else None
     out = {
         "metric": "Mrays/sec (primary+secondary), %dx%d %dspp path trace — pipelined throughput over %d consecutive %d-spp windows of one progressive render (single_render = one such render alone)" % (W, H, SPP, args.steps, SPP),
@@ -302,7 +317,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4),
         "ms_per_frame": round(ms_step / SPP, 5),
-        "higher_is_better": True, "scaling": "weak" if args.split == "frames" else "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if args.split == "frames" else "strong", "vs_baseline": None, "job_shape": job_shape,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_text(args.scene, args.kind, W, H, SPP, args.steps, launches, world, args.split, coll_lib, collective["used"]),
                    "latency_ms_single_step": round(single_ms, 3) if single_ms else None,
@@ -310,11 +325,14 @@ def main():
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
                    "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},
         "single_render": None if not single_ms else {"ms": round(single_ms, 3), "mrays_s": round(counts["rays"] / single_ms / 1e3, 1), "first_ms": round(lat[0], 3), "untuned_ms": round(lat[1], 3),
-                                                     "what": "ONE %dx%d / %d-spp render on an idle GPU: clear, crt_render(1, %d, 1), sync (16 renders; the first 11 let the back end's latency mode measure the tiles and settle, `ms` = median of the last 5, `first_ms` / `untuned_ms` = renders 1 and 2: one wavefront per tile while the tile costs are measured)" % (W, H, SPP, SPP)},
+                                                     "what": "ONE %dx%d / %d-spp render on an idle GPU: clear, crt_render(1, %d, 1), sync (16 renders; the first 11 let the back end's latency mode measure the tiles and settle, `ms` = median of the last 5, `first_ms` / `untuned_ms` = renders 1 and 2: a block table built from the 0.4-ms cost probe that precedes the first render after a camera / scene change, while the tile costs are measured)" % (W, H, SPP, SPP)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "hbm_actual_frac": None if not traffic or job_launch_ms <= 0 else round(traffic / (job_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                     "limiter": "valu_issue (fp32 instruction issue on divergent code; the algorithmic bytes are served by L2: see hbm_actual_frac and valu_issue)",
+                     "useful_lane_issue_frac": None if not valu_instrs or not lane_util or job_launch_ms <= 0 else round(valu_instrs / (job_launch_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GINSTR * lane_util, 4),
+                     "limiter": "instruction issue on divergent fp32 / integer code, NOT HBM: `bound`/`frac` are SURVEY 8(d)'s nominal yardstick (algorithmic bytes against the HBM peak) and reach or exceed 1 only "
+                                "because the 0.75 MB scene is served by L2 (see l2_hit_rate) — the DRAM traffic is hbm_actual_frac of the peak; what grades the kernel is useful_lane_issue_frac = VALU issue rate / issue peak x lane utilisation",
+                     "counters_from": counters_from, "l2_hit_rate": None if l2_hit is None else round(l2_hit, 4),
                      "kernel": job_kernel, "job_split": bool(tm.get("split_launches", 0)), "avg_launch_ms": round(avg_launch_ms, 4), "launches": all_launches,
                      "algorithmic_bytes_per_launch": int(alg_bytes_launch),
                      "job_launch_ms": round(job_launch_ms, 4), "job_launch_windows": round(1 / launches_per_step, 2) if launches_per_step else None,
@@ -323,11 +341,16 @@ def main():
                      "accumulate_kernel_ms_per_step": round(acc_ms / args.steps, 4),
                      "valu_issue": None if not valu_instrs or job_launch_ms <= 0 else {
                          "wave_instructions_per_job_launch": valu_instrs, "achieved_ginstr_s": round(valu_instrs / (job_launch_ms * 1e-3) / 1e9, 1),
-                         "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "frac": round(valu_instrs / (job_launch_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GINSTR, 4),
-                         "lane_utilisation": pmc.get("lane_utilisation") if pmc else None,
-                         "note": "the limiter in practice: SQ_INSTS_VALU of the job's launch (PMC pass, per window x windows of this launch) / its duration, against the chip's measured fp32 VALU issue peak; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)"},
+                         "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "peak_theoretical_ginstr_s": VALU_ISSUE_PEAK_THEORETICAL, "peak_int_cmp_ginstr_s": VALU_INT_PEAK_GINSTR,
+                         "frac": round(valu_instrs / (job_launch_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GINSTR, 4),
+                         "frac_of_theoretical": round(valu_instrs / (job_launch_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_THEORETICAL, 4),
+                         "valu_wave_instructions_per_ray": round(valu_instrs / max(counts["rays"] * windows_per_launch, 1), 3),
+                         "lane_utilisation": None if lane_util is None else round(lane_util, 4),
+                         "note": "SQ_INSTS_VALU of the job's render kernels / the launch's duration; peaks: measured fp32 mul / add / fma / cndmask issue peak of the chip (tools/microbench/valu_peak.hip, profiles/r03_valu_peak.txt: 1 050 G wave-instr/s), "
+                                 "theoretical 256 CU x 4 SIMD x 2.4 GHz / 2 cycles = 1 229 G/s, and the measured rate of integer / compare instructions (shifts, xor, v_cmp: 605 G/s — the RNG and the predicate logic run at half rate); "
+                                 "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)"},
                      "counters_per_step": {k: round(v) for k, v in counts.items()},
-                     "note": "achieved = mean algorithmic bytes per " + job_kernel + " launch / mean launch duration over all its launches in this process (warm-up job + timed job; HIP events on the launch stream) = the average rocprofv3 --stats reports; job_launch_* = the timed job's launch alone (job_split: its most expensive tiles ran beside it in a concurrent render_tiles_kernel launch driven by a block table, inside the same event pair); job_achieved = algorithmic GB/s over the whole timed region incl. the ordered accumulate; the bytes are algorithmic (SURVEY 8(d)) and mostly served by L2 — traffic = HBM bytes of the job's launch from the PMC passes (per window x windows), hbm_actual_frac = traffic / job launch time / peak"},
+                     "note": "achieved = mean algorithmic bytes per " + job_kernel + " launch / mean launch duration over all its launches in this process (warm-up job + timed job; HIP events on the launch stream) = the average rocprofv3 --stats reports; job_launch_* = the timed job's launch alone (job_split: its most expensive tiles ran beside it in a concurrent render_tiles_kernel launch driven by a block table, inside the same event pair); job_achieved = algorithmic GB/s over the whole timed region incl. the ordered accumulate; the bytes are algorithmic (SURVEY 8(d)) and mostly served by L2 — traffic = HBM bytes (FETCH_SIZE + WRITE_SIZE, x 1024) of the job's render kernels per launch from the PMC passes named in counters_from, hbm_actual_frac = traffic / job launch time / peak"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(xml, args.kind, W, H)
