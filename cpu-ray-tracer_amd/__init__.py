@@ -77,7 +77,7 @@ RAY_DTYPE = np.dtype([("O", "<f4", 3), ("D", "<f4", 3), ("inside", "<i4")])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("objIdx", "<i4"), ("triIdx", "<i4"), ("traversed", "<i4"), ("tested", "<i4")])
 
 # every symbol include/crt_abi.h and include/crt_host.h declare (tests check the library exports all of them)
-ABI_SYMBOLS = ["crt_upload_alt_accel", "crt_find_nearest_alt", "crt_update_scene", "crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
+ABI_SYMBOLS = ["crt_set_render_accel", "crt_upload_alt_accel", "crt_find_nearest_alt", "crt_update_scene", "crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
                "crt_render", "crt_reserve", "crt_whitted_tick", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
                "crt_reset_counters", "crt_get_timing", "crt_get_tile_clocks", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
 HOST_SYMBOLS = ["crt_host_scene_build_alt", "crt_host_scene_upload_alt", "crt_host_scene_alt_info", "crt_host_scene_alt_copy", "crt_host_scene_set_transform", "crt_host_scene_update", "crt_host_math_probe", "crt_host_vertex_dedup", "crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
@@ -217,6 +217,10 @@ class Context:
         e = C.c_float()
         self._ck(self.L.crt_resolve_screen(self.h, C.c_float(scale), _p(px), C.byref(e)))
         return px, e.value
+
+    def set_render_accel(self, kind):
+        """crt_set_render_accel: 0 = BVH / TLAS, ACCEL_KDTREE / ACCEL_GRID = Sample and Trace go through the uploaded alternative accelerator"""
+        self._ck(self.L.crt_set_render_accel(self.h, int(kind)))
 
     def find_nearest_alt(self, kind, O, D):
         """scene.FindNearest with FileScene's KD-tree / grid in place of the BVH (crt_find_nearest_alt)"""

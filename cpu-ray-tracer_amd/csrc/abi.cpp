@@ -26,7 +26,9 @@ extern "C" hipError_t crt_launch_probe(const crt::Scene*, uint32_t, uint32_t, ui
 extern "C" hipError_t crt_launch_render_narrow(const crt::Scene*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
-extern "C" hipError_t crt_launch_whitted(const crt::Scene*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
+namespace crt { struct AltAccelDev; }
+extern "C" hipError_t crt_launch_whitted(const crt::Scene*, int, const crt::AltAccelDev*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_render_alt(int, const crt::Scene*, const crt::AltAccelDev*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_resolve(const void*, uint32_t*, float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float, hipStream_t);
 
 static_assert(sizeof(crt_bvh_node) == 32 && sizeof(crt_tri) == 112 && sizeof(crt_tlas_node) == 32, "reference layouts");
@@ -94,6 +96,7 @@ struct crt_ctx {
                   std::vector<uint64_t> pairBase, triBase; std::vector<uint32_t> nodesUsed, triCount; std::vector<char> geom; } flat;
     char* hStage[2] = {nullptr, nullptr}; size_t stageBytes[2] = {0, 0}; hipEvent_t stageCopied[2] = {nullptr, nullptr}; int stageFlip = 0;
     hipEvent_t sceneReady = nullptr;      // recorded behind the last in-place scene update; render launches wait for it on their stream
+    int renderAccel = 0;                  // crt_set_render_accel: 0 = the scene's BVH / TLAS, CRT_ACCEL_KDTREE / CRT_ACCEL_GRID = Sample and Trace go through that structure
     crt::AltAccelDev alt{}; bool haveKd = false, haveGrid = false; std::vector<void*> altAllocs[2]; void* altTris = nullptr; uint32_t altTriCount = 0;   // KD-tree [0] / grid [1] buffers
     void* dQueryRays = nullptr; void* dQueryHits = nullptr; size_t queryCap = 0;      // crt_find_nearest staging (rays)
     // Latency mode of single-window launches (render_tiles_kernel's block table), driven by measurement — see next_block_table.  Stage 0 = one wavefront per tile;
@@ -146,7 +149,7 @@ struct crt_ctx {
     {
         for (auto& v : altAllocs) { for (void* p : v) (void)hipFree(p); v.clear(); }
         if (altTris) (void)hipFree(altTris);
-        altTris = nullptr; altTriCount = 0; haveKd = haveGrid = false; alt = crt::AltAccelDev{};
+        altTris = nullptr; altTriCount = 0; haveKd = haveGrid = false; alt = crt::AltAccelDev{}; renderAccel = 0;
     }
     void freeScene()
     {
@@ -1268,6 +1271,26 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     uint32_t maxF = 0;
     { int r = ensure_pool(c, frames, passes, &maxF); if (r) return r; }
     const size_t windowBytes = window_bytes(c, passes);
+    if (c->renderAccel != 0) {
+        // Renderer::Sample through FileScene's KD-tree / grid (crt_set_render_accel): the sequential form — one wavefront per (tile, window), lane = frame — on the
+        // main stream, followed by the ordered accumulate; no planning, no latency mode (the BASELINE configurations are BVH-SAH; this path exists for parity
+        // with the reference's shipped FileScene, which traces through its KD-tree: file_scene.h:10-12)
+        for (uint32_t f0 = 0; f0 < frames; f0 += maxF) {
+            const uint32_t nf = (frames - f0 < maxF) ? frames - f0 : maxF;
+            size_t off = 0; int r;
+            if ((r = take_region(c, (size_t)((nf + 63u) / 64u) * windowBytes, c->stream, &off))) return r;
+            if (c->sceneReady) HIPCK(c, hipStreamWaitEvent(c->stream, c->sceneReady, 0));
+            void* slab = c->pool + off;
+            HIPCK(c, crt_launch_render_alt(c->renderAccel, &c->hScene, &c->alt, slab, c->dCounters, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->stream));
+            HIPCK(c, crt_launch_accumulate(slab, c->dAcc, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, (uint32_t)c->cfg.width, nf, passes, c->stream));
+            crt_ctx::Region reg; reg.off = off; reg.bytes = (size_t)((nf + 63u) / 64u) * windowBytes;
+            if (c->freeEvents.empty()) HIPCK(c, hipEventCreateWithFlags(&reg.freed, hipEventDisableTiming));
+            else { reg.freed = c->freeEvents.back(); c->freeEvents.pop_back(); }
+            HIPCK(c, hipEventRecord(reg.freed, c->stream));
+            c->inflight.push_back(reg);
+        }
+        return CRT_OK;
+    }
     for (uint32_t f0 = 0; f0 < frames; f0 += maxF) {
         const uint32_t nf = (frames - f0 < maxF) ? frames - f0 : maxF;
         hipStream_t st = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
@@ -1474,7 +1497,7 @@ int crt_whitted_tick(crt_ctx* c, uint32_t* hostPixels)
     if (!c) return CRT_ERR_INVALID;
     if (!c->haveScene) return c->fail(CRT_ERR_STATE, "crt_whitted_tick before crt_upload_scene");
     HIPCK(c, hipSetDevice(c->cfg.device));
-    HIPCK(c, crt_launch_whitted(&c->hScene, c->dAcc, c->dPixels, c->dCounters, c->ldsBytes, c->stream));
+    HIPCK(c, crt_launch_whitted(&c->hScene, c->renderAccel, &c->alt, c->dAcc, c->dPixels, c->dCounters, c->ldsBytes, c->stream));
     if (hostPixels) HIPCK(c, hipMemcpyAsync(hostPixels, c->dPixels, (size_t)c->cfg.width * c->cfg.height * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
@@ -1542,6 +1565,7 @@ int crt_upload_alt_accel(crt_ctx* c, const crt_alt_accel* a)
     for (void* p : c->altAllocs[slot]) (void)hipFree(p);
     c->altAllocs[slot].clear();
     if (slot == 0) c->haveKd = false; else c->haveGrid = false;
+    if (c->renderAccel == a->kind) c->renderAccel = 0;
     auto up = [&](const void* src, size_t bytes, const void** out) -> int {
         *out = nullptr; if (!bytes) return 0;
         void* d = nullptr; HIPCK(c, hipMalloc(&d, bytes)); c->altAllocs[slot].push_back(d);
@@ -1575,6 +1599,16 @@ int crt_upload_alt_accel(crt_ctx* c, const crt_alt_accel* a)
         for (int k = 0; k < 3; k++) { c->alt.res[k] = a->gridResolution[k]; c->alt.cell[k] = a->gridCellSize[k]; c->alt.lo[k] = a->gridMin[k]; c->alt.hi[k] = a->gridMax[k]; }
         c->haveGrid = true;
     }
+    return CRT_OK;
+}
+
+int crt_set_render_accel(crt_ctx* c, int kind)
+{
+    if (!c) return CRT_ERR_INVALID;
+    if (kind != 0 && kind != CRT_ACCEL_KDTREE && kind != CRT_ACCEL_GRID) return c->fail(CRT_ERR_INVALID, "crt_set_render_accel: unknown accelerator kind %d", kind);
+    if ((kind == CRT_ACCEL_KDTREE && !c->haveKd) || (kind == CRT_ACCEL_GRID && !c->haveGrid)) return c->fail(CRT_ERR_STATE, "crt_set_render_accel: no such accelerator uploaded (kind %d)", kind);
+    if (kind != 0 && (c->alt.kdStack * 2u + 15u) * 64u * 4u * 4u > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "KD-tree height %u exceeds the render kernel's LDS stack", c->alt.kdStack);
+    c->renderAccel = kind;
     return CRT_OK;
 }
 

@@ -20,7 +20,7 @@
 // Numerics: compiled with -ffp-contract=off; only IEEE + - * / sqrt, so results are bit-identical with a scalar
 // CPU evaluation of the same expressions.  min/max follow the reference's std::min/std::max operand order.
 // No MFMA: the path is pointer chasing + slab / Möller–Trumbore tests.
-#include "dev_common.h"
+#include "alt_common.h"
 
 namespace crt {
 
@@ -569,7 +569,8 @@ __global__ __launch_bounds__(64) void find_nearest_kernel(const Scene sc, const 
 struct WFrame { f3 cA, cB, C, medium, out, bO, bD; int flags; };     // flags: 1 hasA, 2 hasB, 4 hasC, 8 b.inside, 16 waiting for B
 constexpr int kWhittedMaxDepth = 7;
 
-__device__ __forceinline__ bool whitted_occluded(const Scene& sc, f3 O, f3 D, float tmax, uint32_t* stk, Cnt& cn)   // FileScene::IsOccluded, file_scene.cpp:177-187
+template <int ACCEL>
+__device__ __forceinline__ bool whitted_occluded(const Scene& sc, const AltAccelDev& alt, f3 O, f3 D, float tmax, uint32_t* stk, Cnt& cn)   // FileScene::IsOccluded, file_scene.cpp:177-187
 {
     {   // Quad::IsOccluded, primitives.h:347-362
         const float* c = sc.lightInvT;
@@ -591,7 +592,9 @@ __device__ __forceinline__ bool whitted_occluded(const Scene& sc, f3 O, f3 D, fl
     const f3 rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
     int traversed = 0, tested = 0;
     cn.rays++;
-    if (sc.kind == 0) traverse_bvh_seq(sc, sc.rootRef, O, D, rD, h, stk, cn, traversed, tested);
+    if (ACCEL == 1) kd_intersect(alt, O, D, rD, h, stk, traversed, tested);          // (stk: this lane's column, two words per entry)
+    else if (ACCEL == 2) grid_intersect(alt, O, D, rD, h, traversed, tested);
+    else if (sc.kind == 0) traverse_bvh_seq(sc, sc.rootRef, O, D, rD, h, stk, cn, traversed, tested);
     else {
         Hit hh = h; Cnt dummy = cn;
         // TLAS walk without the quad / plane tests: reuse find_nearest_seq's TLAS part through a light-less copy is not possible, so inline it
@@ -623,7 +626,9 @@ __device__ __forceinline__ bool whitted_occluded(const Scene& sc, f3 O, f3 D, fl
     return h.objIdx > -1;
 }
 
-__global__ __launch_bounds__(64) void whitted_kernel(const Scene sc, float4* __restrict__ acc, uint32_t* __restrict__ pixels, Counters* __restrict__ counters)
+// ACCEL: 0 = the scene's BVH / TLAS, 1 / 2 = FileScene's KD-tree / uniform grid (crt_set_render_accel) for both the nearest-hit and the shadow queries
+template <int ACCEL>
+__global__ __launch_bounds__(64) void whitted_kernel(const Scene sc, const AltAccelDev alt, float4* __restrict__ acc, uint32_t* __restrict__ pixels, Counters* __restrict__ counters)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -654,7 +659,13 @@ __global__ __launch_bounds__(64) void whitted_kernel(const Scene sc, float4* __r
                     Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
                     const f3 rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);
                     int traversed = 0, tested = 0;
-                    find_nearest_seq(sc, O, D, rD, h, stk, cn, traversed, tested);
+                    if (ACCEL == 0) find_nearest_seq(sc, O, D, rD, h, stk, cn, traversed, tested);
+                    else {
+                        cn.rays++;
+                        hit_light_floor(sc, O, D, h);
+                        if (ACCEL == 1) kd_intersect(alt, O, D, rD, h, stk, traversed, tested); else grid_intersect(alt, O, D, rD, h, traversed, tested);
+                        if (h.objIdx >= 2) cn.meshhits++;
+                    }
                     if (h.objIdx == -1) res = sky_color(sc, D);
                     else if (h.objIdx == 0) res = mk3(24, 24, 22);
                     else {
@@ -718,7 +729,7 @@ __global__ __launch_bounds__(64) void whitted_kernel(const Scene sc, float4* __r
                             L = L * (1 / dist);
                             const float ndotl = dot3(N, L);
                             if (!(ndotl < CRT_EPS)) {
-                                if (!whitted_occluded(sc, I + L * CRT_EPS, L, dist - 2 * CRT_EPS, stk, cn)) {
+                                if (!whitted_occluded<ACCEL>(sc, alt, I + L * CRT_EPS, L, dist - 2 * CRT_EPS, stk, cn)) {
                                     const float att = 1 / (dist * dist);
                                     const f3 inr = mk3(24, 24, 22) * att;
                                     irr = inr * dot3(N, L);
@@ -859,11 +870,13 @@ extern "C" hipError_t crt_launch_find_nearest(const crt::Scene* sc, const void* 
     return hipGetLastError();
 }
 
-extern "C" hipError_t crt_launch_whitted(const crt::Scene* sc, void* acc, uint32_t* pixels, crt::Counters* counters, uint32_t ldsBytes, hipStream_t stream)
+extern "C" hipError_t crt_launch_whitted(const crt::Scene* sc, int accel, const crt::AltAccelDev* alt, void* acc, uint32_t* pixels, crt::Counters* counters, uint32_t ldsBytes, hipStream_t stream)
 {
     const uint32_t n = (uint32_t)sc->W * (uint32_t)sc->H;
     dim3 grid((n + 63u) / 64u), block(64);
-    hipLaunchKernelGGL(crt::whitted_kernel, grid, block, ldsBytes, stream, *sc, (float4*)acc, pixels, counters);
+    if (accel == 1) hipLaunchKernelGGL(crt::whitted_kernel<1>, grid, block, alt->kdStack * 128u * 4u, stream, *sc, *alt, (float4*)acc, pixels, counters);
+    else if (accel == 2) hipLaunchKernelGGL(crt::whitted_kernel<2>, grid, block, 256u, stream, *sc, *alt, (float4*)acc, pixels, counters);
+    else { const crt::AltAccelDev none{}; hipLaunchKernelGGL(crt::whitted_kernel<0>, grid, block, ldsBytes, stream, *sc, none, (float4*)acc, pixels, counters); }
     return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@
 // Two-level scenes walk TLAS and BLAS with the sequential reference-order traversal of dev_common.h (find_nearest_seq), without the speculation.
 //
 // Numerics: -ffp-contract=off, IEEE + - * / sqrt only (dev_common.h).  No MFMA: pointer chasing + slab / Möller–Trumbore tests.
-#include "dev_common.h"
+#include "alt_common.h"
 
 namespace crt {
 
@@ -36,20 +36,25 @@ constexpr uint32_t kNarrowWaves = 4u;                      // wavefronts per wor
 // PROBE = true is the cost probe of the latency mode (abi.cpp probe_tile_costs): one wavefront per tile, lane l traces ONE path through pixel (2 (l % 8), 2 (l / 8)) of the
 // tile with a seed of its own, nothing is stored, and the wavefront leaves the number of traversal / shading steps its 64 paths took in tileCost[tile] — an estimate of
 // what the tile's streams will cost (a stream = 256 such paths), available ~0.3 ms after a camera or scene change instead of after a first full render.
-template <int KIND, bool PROBE>
-__global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, float4* __restrict__ slab, Counters* __restrict__ counters,
+// MODE 0 = block-table wavefronts of <= kNarrowMaxLanes lanes (above), MODE 1 = the cost probe (PROBE),
+// MODE 2 / 3 = whole (tile, window) wavefronts, lane = frame, that trace Renderer::Sample through FileScene's KD-tree / uniform grid instead of the BVH
+// (crt_set_render_accel: the reference's shipped FileScene traces through the KD-tree, file_scene.h:10-12, file_scene.cpp:170-175) — the sequential form:
+// entry = tile rank * windows + window.
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, const AltAccelDev acc, float4* __restrict__ slab, Counters* __restrict__ counters,
                                                               uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX,
                                                               uint32_t sppFirst, uint32_t frames, uint32_t passes,
                                                               const uint32_t* __restrict__ blockDesc, uint32_t nBlocks, uint32_t* __restrict__ tileCost)
 {
+    constexpr bool PROBE = MODE == 1, ALT = MODE >= 2;
     extern __shared__ uint32_t ldsAll[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long clk0 = tileCost ? wall_clock64() : 0ull;
     const char* __restrict__ geom = sc.geom;
     // the treetop into LDS, by all 256 threads (FileScene only)
     const rec4* ldsTop = reinterpret_cast<const rec4*>(ldsAll);
-    const uint32_t topDwords = (KIND == 0 && !PROBE) ? sc.topCount * 16u : 0u;
-    if (KIND == 0 && !PROBE && sc.topCount) {
+    const uint32_t topDwords = (KIND == 0 && MODE == 0) ? sc.topCount * 16u : 0u;
+    if (KIND == 0 && MODE == 0 && sc.topCount) {
         rec4* dst = reinterpret_cast<rec4*>(ldsAll);
         for (uint32_t i = threadIdx.x; i < sc.topCount * 4u; i += 256u) dst[i] = ldg(geom, sc.topOff + i * 16u);
         __syncthreads();
@@ -57,9 +62,10 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
     // blockDesc[block] = local tile index | first frame << 16 | log2(lanes) << 22 | window << 25 (the table format of render_tiles_kernel; abi.cpp)
     const uint32_t entry = blockIdx.x * kNarrowWaves + wave;
     if (entry >= nBlocks) return;
-    const uint32_t d = PROBE ? (entry | (6u << 22)) : blockDesc[entry];          // (probe: block = tile, all 64 lanes)
+    const uint32_t windowsAll = (frames + 63u) / 64u;
+    const uint32_t d = PROBE ? (entry | (6u << 22)) : ALT ? ((entry / windowsAll) | (6u << 22) | ((entry % windowsAll) << 25)) : blockDesc[entry];   // (probe / accelerator modes: all 64 lanes)
     const uint32_t tl = d & 0xffffu, laneBase = (d >> 16) & 63u, myLanes = 1u << ((d >> 22) & 7u), win = d >> 25;
-    if (tl >= tileCount || (!PROBE && myLanes > kNarrowMaxLanes)) return;
+    if (tl >= tileCount || (MODE == 0 && myLanes > kNarrowMaxLanes)) return;
     sppFirst += win * 64u * passes;
     frames = (frames - win * 64u < 64u) ? frames - win * 64u : 64u;               // frames of THIS window (the last one may be partial)
     frames = frames > laneBase ? ((frames - laneBase < myLanes) ? frames - laneBase : myLanes) : 0u;
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
     const uint32_t tile = tileFirst + tl * tileStride;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     // this wavefront's LDS behind the treetop
-    uint32_t* lds = ldsAll + topDwords + wave * ((KIND == 0 && !PROBE) ? kNarrowMaxLanes * narrow_lane_dwords(sc.stackDepth) : (sc.stackDepth + 15u) * 64u);
+    uint32_t* lds = ldsAll + topDwords + wave * ((KIND == 0 && MODE == 0) ? kNarrowMaxLanes * narrow_lane_dwords(sc.stackDepth) : ALT ? (acc.kdStack * 2u + 15u) * 64u : (sc.stackDepth + 15u) * 64u);
 
     uint32_t nRays = 0, nPrimary = 0, nMesh = 0;
     const uint32_t items = PROBE ? 1u : 256u * passes;                            // (pixel, pass) pairs in stream order
@@ -78,12 +84,12 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
 
     // LDS of this lane
     uint32_t* refStk; rec4* recStk; float* fst; uint32_t* seqStk = nullptr; uint32_t fstStride;
-    if (KIND == 0 && !PROBE) {
+    if (KIND == 0 && MODE == 0) {
         uint32_t* mine = lds + lane * narrow_lane_dwords(sc.stackDepth);
         recStk = reinterpret_cast<rec4*>(mine); refStk = mine + sc.stackDepth * 16u; fst = reinterpret_cast<float*>(refStk + sc.stackDepth); fstStride = 1u;
     } else {
-        seqStk = lds + lane; refStk = nullptr; recStk = nullptr;                  // find_nearest_seq's column layout: entry i at [i * 64]
-        fst = reinterpret_cast<float*>(lds + sc.stackDepth * 64u + lane); fstStride = 64u;
+        seqStk = lds + lane; refStk = nullptr; recStk = nullptr;                  // find_nearest_seq's column layout: entry i at [i * 64] (KD-tree: two words per entry, [i * 128] and [i * 128 + 64])
+        fst = reinterpret_cast<float*>(lds + (ALT ? acc.kdStack * 2u : sc.stackDepth) * 64u + lane); fstStride = 64u;
     }
 
     const kernarg_f cam = scene_floats(offsetof(Scene, camPos));                  // camPos, topLeft, topRight, bottomLeft, invW, invH
@@ -109,7 +115,12 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, f
             const f3 rD = rcp_exact3(D);
             Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
             nRays++;
-            if (KIND == 1 || PROBE) {
+            if (ALT) {
+                int traversed = 0, tested = 0;
+                hit_light_floor(sc, O, D, h);                                      // FileScene::FindNearest: light quad, floor plane, then the accelerator
+                if (MODE == 2) kd_intersect(acc, O, D, rD, h, seqStk, traversed, tested);
+                else grid_intersect(acc, O, D, rD, h, traversed, tested);
+            } else if (KIND == 1 || PROBE) {
                 Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
                 int traversed = 0, tested = 0;
                 find_nearest_seq(sc, O, D, rD, h, seqStk, cn, traversed, tested);
@@ -286,12 +297,13 @@ extern "C" hipError_t crt_launch_render_narrow(const crt::Scene* sc, void* slab,
 {
     if (tileCount == 0 || frames == 0 || nBlocks == 0 || !blockDesc) return hipSuccess;
     (void)ldsTiles;
+    const crt::AltAccelDev none{};
     dim3 grid((nBlocks + crt::kNarrowWaves - 1u) / crt::kNarrowWaves), block(64u * crt::kNarrowWaves);
     if (sc->kind == 0) {
         const uint32_t ldsBytes = sc->topCount * 64u + crt::kNarrowWaves * crt::kNarrowMaxLanes * crt::narrow_lane_dwords(sc->stackDepth) * 4u;
-        hipLaunchKernelGGL((crt::render_narrow_kernel<0, false>), grid, block, ldsBytes, stream, *sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, blockDesc, nBlocks, tileCost);
+        hipLaunchKernelGGL((crt::render_narrow_kernel<0, 0>), grid, block, ldsBytes, stream, *sc, none, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, blockDesc, nBlocks, tileCost);
     } else
-        hipLaunchKernelGGL((crt::render_narrow_kernel<1, false>), grid, block, crt::kNarrowWaves * (sc->stackDepth + 15u) * 64u * 4u, stream, *sc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, blockDesc, nBlocks, tileCost);
+        hipLaunchKernelGGL((crt::render_narrow_kernel<1, 0>), grid, block, crt::kNarrowWaves * (sc->stackDepth + 15u) * 64u * 4u, stream, *sc, none, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, blockDesc, nBlocks, tileCost);
     return hipGetLastError();
 }
 
@@ -299,9 +311,27 @@ extern "C" hipError_t crt_launch_render_narrow(const crt::Scene* sc, void* slab,
 extern "C" hipError_t crt_launch_probe(const crt::Scene* sc, uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t* tileCost, hipStream_t stream)
 {
     if (tileCount == 0 || !tileCost || tileCount > 0x10000u) return hipSuccess;
+    const crt::AltAccelDev none{};
     dim3 grid((tileCount + crt::kNarrowWaves - 1u) / crt::kNarrowWaves), block(64u * crt::kNarrowWaves);
     const uint32_t ldsBytes = crt::kNarrowWaves * (sc->stackDepth + 15u) * 64u * 4u;
-    if (sc->kind == 0) hipLaunchKernelGGL((crt::render_narrow_kernel<0, true>), grid, block, ldsBytes, stream, *sc, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, tileCount, tileCost);
-    else hipLaunchKernelGGL((crt::render_narrow_kernel<1, true>), grid, block, ldsBytes, stream, *sc, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, tileCount, tileCost);
+    if (sc->kind == 0) hipLaunchKernelGGL((crt::render_narrow_kernel<0, 1>), grid, block, ldsBytes, stream, *sc, none, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, tileCount, tileCost);
+    else hipLaunchKernelGGL((crt::render_narrow_kernel<1, 1>), grid, block, ldsBytes, stream, *sc, none, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, tileCount, tileCost);
+    return hipGetLastError();
+}
+
+// Renderer::Sample through FileScene's KD-tree (accel 1) or uniform grid (accel 2): one wavefront per (owned tile, 64-frame window) of the launch, lane = frame
+extern "C" hipError_t crt_launch_render_alt(int accel, const crt::Scene* sc, const crt::AltAccelDev* acc, void* slab, crt::Counters* counters, uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount,
+                                            uint32_t tilesX, uint32_t sppFirst, uint32_t frames, uint32_t passes, hipStream_t stream)
+{
+    if (tileCount == 0 || frames == 0) return hipSuccess;
+    if (sc->kind != 0 || (accel != 1 && accel != 2)) return hipErrorInvalidValue;
+    const uint32_t windows = (frames + 63u) / 64u;
+    if ((unsigned long long)tileCount * windows > 0x7fffffffull || tileCount > 0x10000u || windows > 64u) return hipErrorInvalidValue;
+    const uint32_t entries = tileCount * windows;
+    dim3 grid((entries + crt::kNarrowWaves - 1u) / crt::kNarrowWaves), block(64u * crt::kNarrowWaves);
+    const uint32_t ldsBytes = crt::kNarrowWaves * (acc->kdStack * 2u + 15u) * 64u * 4u;
+    if (ldsBytes > 64u * 1024u) return hipErrorInvalidValue;
+    if (accel == 1) hipLaunchKernelGGL((crt::render_narrow_kernel<0, 2>), grid, block, ldsBytes, stream, *sc, *acc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, (const uint32_t*)nullptr, entries, (uint32_t*)nullptr);
+    else hipLaunchKernelGGL((crt::render_narrow_kernel<0, 3>), grid, block, ldsBytes, stream, *sc, *acc, (float4*)slab, counters, tileFirst, tileStride, tileCount, tilesX, sppFirst, frames, passes, (const uint32_t*)nullptr, entries, (uint32_t*)nullptr);
     return hipGetLastError();
 }

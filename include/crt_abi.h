@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 2
+#define CRT_ABI_VERSION 3
 
 typedef enum crt_status {
     CRT_OK = 0,
@@ -208,6 +208,11 @@ typedef struct crt_alt_accel {
 } crt_alt_accel;
 int  crt_upload_alt_accel(crt_ctx* ctx, const crt_alt_accel* accel);   /* after crt_upload_scene of a CRT_SCENE_FILE scene; one structure per kind is kept */
 int  crt_find_nearest_alt(crt_ctx* ctx, int kind, const crt_ray* rays, crt_hit* hits, size_t n);
+/* ABI 3: which structure crt_render (Renderer::Sample) and crt_whitted_tick (Renderer::Trace, incl. its shadow rays) trace through: 0 = the scene's BVH / TLAS
+ * (default), CRT_ACCEL_KDTREE / CRT_ACCEL_GRID = the uploaded alternative accelerator — what the reference's FileScene does when built with USE_KDTree (its shipped
+ * setting, infra/scene/file_scene.h:10-12, file_scene.cpp:170-187) / USE_Grid.  Bug-compatible: the KD traversal loses hits for rays with a direction component of
+ * exactly 0 (kdtree.cpp:161-201).  The sequential form (one wavefront per tile and 64-frame window); reset by crt_upload_scene / crt_upload_alt_accel of the kind. */
+int  crt_set_render_accel(crt_ctx* ctx, int kind);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
 int  crt_get_counters(crt_ctx* ctx, crt_counters* out);        /* cumulative since create / crt_reset_counters       */

@@ -639,6 +639,8 @@ struct HitInfo { V3 N; V2 uv; const Mat* mat; };
 // ------------------------------------------------------------------------------------------------
 // context = scene (FileScene | TLASFileScene) + Renderer state
 // ------------------------------------------------------------------------------------------------
+// FileScene built with USE_KDTree / USE_Grid (infra/scene/file_scene.h:10-12): `acc` of FindNearest / IsOccluded is that structure (defined at the end of this file)
+
 struct orc_ctx {
     int kind = 0;
     std::string err;
@@ -664,15 +666,23 @@ struct orc_ctx {
     Counters counters;
     std::vector<uint32_t> tileSeedOut; int tileSeedSpp = -1;
 
+    void (*accelFn)(void*, Ray&) = nullptr;     // (set by orc_set_render_accel, where KdTree / UGrid are defined)
+    int accel = 0; void* accelH = nullptr;      // orc_set_render_accel: 0 = BVH / TLAS, 1 = KD-tree, 2 = grid (a FileScene's `acc`; handle of orc_kd_build / orc_grid_build)
+
     ~orc_ctx() { for (Bvh* b : bvhs) delete b; }
 
     // ---- scene queries ----
+    void accel_intersect(Ray& r, Counters& cn) const   // acc.Intersect(ray): file_scene.cpp:174, 183
+    {
+        if (kind == 0 && accel != 0) accelFn(accelH, r);
+        else if (kind == 0) bvhs[0]->traverse(r, cn); else tlas.traverse(r, cn);
+    }
     void find_nearest(Ray& r, Counters& cn) const // file_scene.cpp:170-175, tlas_file_scene.cpp:201-206
     {
         cn.rays++;
         light.intersect(r);
         floor.intersect(r);
-        if (kind == 0) bvhs[0]->traverse(r, cn); else tlas.traverse(r, cn);
+        accel_intersect(r, cn);
         if (r.objIdx >= 2) cn.meshhits++;
     }
     V3 sky_color(const Ray& r) const // file_scene.cpp:142-154
@@ -1172,7 +1182,7 @@ struct Whitted {
         if (c->light.occluded(ray)) return true;
         Ray sh = ray; sh.t = 1e34f;
         cn.rays++;
-        if (c->kind == 0) c->bvhs[0]->traverse(sh, cn); else c->tlas.traverse(sh, cn);
+        c->accel_intersect(sh, cn);
         return sh.objIdx > -1;
     }
     V3 direct(V3 I, V3 N)
@@ -1439,6 +1449,13 @@ struct UGrid {
 };
 } // namespace
 
+int orc_set_render_accel(orc_ctx* c, int kind, void* h)      // kind 1: h = orc_kd_build(..), 2: orc_grid_build(..) over the scene's triangle array (orc_bvh_copy order); 0: the BVH again
+{
+    if (!c || kind < 0 || kind > 2 || (kind != 0 && (!h || c->kind != 0))) return -1;
+    c->accel = kind; c->accelH = kind ? h : nullptr;
+    c->accelFn = kind == 1 ? +[](void* p, Ray& r) { ((KdTree*)p)->intersect(r, 0); } : +[](void* p, Ray& r) { ((UGrid*)p)->intersect(r); };
+    return 0;
+}
 void* orc_kd_build(const orc_tri* tris, uint32_t n) { KdTree* k = new KdTree(); k->tris.assign(tris, tris + n); k->build(); return k; }
 void orc_kd_info(void* h, uint32_t* nodes, uint32_t* refs, uint32_t* maxDepth, uint32_t* nodesUsed) { KdTree* k = (KdTree*)h; *nodes = (uint32_t)k->nodes.size(); *refs = (uint32_t)k->refs.size(); *maxDepth = k->maxDepth; *nodesUsed = k->nodesUsed; }
 void orc_kd_dump(void* h, orc_kd_node* nodes, uint32_t* refs) { KdTree* k = (KdTree*)h; memcpy(nodes, k->nodes.data(), k->nodes.size() * sizeof(orc_kd_node)); memcpy(refs, k->refs.data(), k->refs.size() * 4); }

@@ -119,6 +119,8 @@ void orc_grid_info(void* h, int32_t res[3], float cell[3], float lo[3], float hi
 void orc_grid_dump(void* h, uint32_t* cellStart, int32_t* refs);
 void orc_grid_intersect(void* h, const float* O, const float* D, uint32_t n, orc_hit* out);
 void orc_grid_free(void* h);
+/* Sample / Trace through the KD-tree (1) or grid (2) of a FileScene instead of its BVH (file_scene.h:10-12): h = the structure built over the scene's triangles */
+int orc_set_render_accel(orc_ctx*, int kind, void* h);
 void orc_math_probe(const float* in12, uint32_t n, float* out120);
 uint32_t orc_vertex_dedup(const float* v8, uint32_t n, uint32_t* idx, float* unique8);
 float orc_expf(float x);

@@ -604,6 +604,14 @@ class AltAccel:
             getattr(self.L, self.p + "_free")(self.h); self.h = None
 
 
+def set_render_accel(scene, accel):
+    """scene: an oracle scene (load_scene); accel: None (BVH again) or an AltAccel of the oracle built over scene.bvh(0)["tris"] — Sample / Trace then go through it"""
+    L = lib()
+    r = L.orc_set_render_accel(scene.h, C.c_int(0 if accel is None else (1 if accel.kind == "kd" else 2)), None if accel is None else accel.h)
+    if r != 0:
+        raise RuntimeError("orc_set_render_accel refused")
+
+
 def alt_accel(kind, tris):
     """the oracle's KDTree ("kd") / Grid ("grid") over `tris`"""
     return AltAccel(lib(), "orc_", kind, tris)

@@ -80,3 +80,39 @@ def test_alt_accel_edge_cases_and_errors(crt, orc, tmp_path):
         for f in ("t", "u", "v", "triIdx"):
             assert np.array_equal(h[f][mesh].view(np.uint32), w[f][mesh].view(np.uint32)), (kind, f)
     ctx.close()
+
+
+@pytest.mark.parametrize("kind,code", [("kd", 1), ("grid", 2)])
+def test_render_through_the_alternative_accelerator(crt, orc, kind, code):
+    """the reference's shipped FileScene traces Sample through its KD-tree (file_scene.h:10-12, file_scene.cpp:170-175).  crt_set_render_accel routes
+    crt_render and crt_whitted_tick through the uploaded KD-tree / grid; the images must be the oracle's when IT renders through its own restatement of the same
+    structure (whose build and traversal are pinned to the real kdtree.cpp / grid.cpp) — and the path tracer's image equals the BVH image here, because the three
+    structures return the same nearest hits for these rays (test above) and consume the same random numbers."""
+    W, H, frames = 96, 64, 5
+    xml = os.path.join(ASSETS, "scenes", "bunny_scene.xml")
+    hs = crt.HostScene(xml, 0, ASSETS)
+    hs.build_alt(code)
+    ctx = crt.Context(W, H); hs.upload(ctx)
+    with pytest.raises(crt.CrtError):
+        ctx.set_render_accel(code)                                   # not uploaded yet
+    hs.upload_alt(ctx, code)
+    o, _ = orc.load_scene(xml, 0, ASSETS); o.renderer_init(W, H)
+    acc = orc.alt_accel(kind, o.bvh(0)["tris"])
+    orc.set_render_accel(o, acc)
+    ctx.set_render_accel(code)
+    ctx.render(1, frames, 1); o.render(frames, 2)
+    got = ctx.accumulator()
+    assert np.array_equal(got, o.accumulator())
+    assert ctx.counters()["rays"] == o.counters()["rays"]
+    # Whitted: Trace and its shadow rays through the same structure
+    px = ctx.whitted_tick(); o.whitted(2)
+    assert np.array_equal(ctx.accumulator(), o.accumulator()) and np.array_equal(px, o.screen())
+    # back to the BVH: the same path-traced image (same hits, same random numbers), and a partial window + two passes through the accelerator
+    ctx.set_render_accel(0); orc.set_render_accel(o, None)
+    ctx.clear(); ctx.render(1, frames, 1)
+    assert np.array_equal(ctx.accumulator(), got)
+    ctx.set_render_accel(code); orc.set_render_accel(o, acc)
+    o.clear(); o.set_params(5, 2); o.render(70, 4)
+    ctx.clear(); ctx.render(1, 70, 2)
+    assert np.array_equal(ctx.accumulator(), o.accumulator())
+    acc.close()
