@@ -77,10 +77,10 @@ RAY_DTYPE = np.dtype([("O", "<f4", 3), ("D", "<f4", 3), ("inside", "<i4")])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("objIdx", "<i4"), ("triIdx", "<i4"), ("traversed", "<i4"), ("tested", "<i4")])
 
 # every symbol include/crt_abi.h and include/crt_host.h declare (tests check the library exports all of them)
-ABI_SYMBOLS = ["crt_set_render_accel", "crt_upload_alt_accel", "crt_find_nearest_alt", "crt_update_scene", "crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
+ABI_SYMBOLS = ["crt_upload_primitive_scene", "crt_set_render_accel", "crt_upload_alt_accel", "crt_find_nearest_alt", "crt_update_scene", "crt_abi_version", "crt_device_count", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
                "crt_render", "crt_reserve", "crt_whitted_tick", "crt_sync", "crt_clear", "crt_read_accumulator", "crt_resolve_screen", "crt_find_nearest", "crt_get_counters",
                "crt_reset_counters", "crt_get_timing", "crt_get_tile_clocks", "crt_bind_accumulator", "crt_accumulator_device_ptr"]
-HOST_SYMBOLS = ["crt_host_scene_build_alt", "crt_host_scene_upload_alt", "crt_host_scene_alt_info", "crt_host_scene_alt_copy", "crt_host_scene_set_transform", "crt_host_scene_update", "crt_host_math_probe", "crt_host_vertex_dedup", "crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
+HOST_SYMBOLS = ["crt_host_primitive_scene_create", "crt_host_primitive_scene_free", "crt_host_primitive_scene_set_time", "crt_host_primitive_scene_desc", "crt_host_primitive_scene_upload", "crt_host_scene_build_alt", "crt_host_scene_upload_alt", "crt_host_scene_alt_info", "crt_host_scene_alt_copy", "crt_host_scene_set_transform", "crt_host_scene_update", "crt_host_math_probe", "crt_host_vertex_dedup", "crt_host_last_error", "crt_host_scene_load", "crt_host_scene_free", "crt_host_scene_upload", "crt_host_scene_kind",
                 "crt_host_scene_triangle_count", "crt_host_scene_bvh_count", "crt_host_scene_bvh_info", "crt_host_scene_bvh_copy",
                 "crt_host_scene_bvh_move_and_refit", "crt_host_scene_blas_transform", "crt_host_scene_tlas_copy", "crt_host_camera_state", "crt_host_renderer_create",
                 "crt_host_renderer_destroy", "crt_host_renderer_init", "crt_host_renderer_set_camera", "crt_host_renderer_set_passes",
@@ -393,6 +393,48 @@ class HostScene:
         nu = C.c_uint32()
         self._ck(self.L.crt_host_scene_tlas_copy(self.h, _p(nodes), C.byref(nu)))
         return nodes, nu.value
+
+
+class PrimitiveSceneS(C.Structure):
+    _fields_ = [("quadT", C.c_float * 16), ("quadInvT", C.c_float * 16), ("quadSize", C.c_float), ("spherePos", C.c_float * 3),
+                ("cubeMin", C.c_float * 3), ("cubeMax", C.c_float * 3), ("cubeM", C.c_float * 16), ("cubeInvM", C.c_float * 16),
+                ("torusT", C.c_float * 16), ("torusInvT", C.c_float * 16), ("torusRt2", C.c_float), ("torusRc2", C.c_float), ("torusR2", C.c_float),
+                ("reflectivity", C.c_float * 11), ("refractivity", C.c_float * 11), ("absorption", C.c_float * 33), ("red", TextureS), ("blue", TextureS)]
+
+
+class HostPrimitiveScene:
+    """PrimitiveScene of the reference (infra/scene/primitive_scene.cpp): constructor, SetTime, upload through crt_upload_primitive_scene"""
+
+    def __init__(self, assets_dir=None):
+        self.L = lib()
+        h = C.c_void_p()
+        r = self.L.crt_host_primitive_scene_create(assets_dir.encode() if assets_dir else None, C.byref(h))
+        if r != 0:
+            raise CrtError(r, self.L.crt_host_last_error().decode())
+        self.h = h
+
+    def set_time(self, t):
+        self.L.crt_host_primitive_scene_set_time(self.h, C.c_float(t))
+
+    def desc(self):
+        d = PrimitiveSceneS()
+        self.L.crt_host_primitive_scene_desc(self.h, C.byref(d))
+        return d
+
+    def state(self):
+        """the 108 floats of the oracle's orc_prim_state: quad T, invT, cube M, invM, torus T, invT, sphere position, rt2, rc2, r2, cube box"""
+        d = self.desc()
+        return np.array(list(d.quadT) + list(d.quadInvT) + list(d.cubeM) + list(d.cubeInvM) + list(d.torusT) + list(d.torusInvT) + list(d.spherePos)
+                        + [d.torusRt2, d.torusRc2, d.torusR2] + list(d.cubeMin) + list(d.cubeMax), np.float32)
+
+    def upload(self, ctx):
+        r = self.L.crt_host_primitive_scene_upload(self.h, ctx.h)
+        if r != 0:
+            raise CrtError(r, self.L.crt_last_error(ctx.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.crt_host_primitive_scene_free(self.h); self.h = None
 
 
 class HostRenderer:

@@ -45,6 +45,14 @@ struct AltAccelDev {
     int32_t res[3]; float cell[3]; float lo[3], hi[3]; const uint32_t* cellStart; const int32_t* cellRefs;
 };
 }
+namespace crt {
+struct PrimDev {                          // = device/render_prim.hip
+    float quadInvT[12], quadNrm[3], quadSize; float spherePos[3], pad0; float cubeInvM[12], cubeM[12], cubeMin[3], cubeMax[3];
+    float torusInvT[12], torusT[12], rt2, rc2, r2, pad1; float refl[11], refr[11], absorb[33]; float pad2; const uint32_t* red; const uint32_t* blue;
+};
+}
+extern "C" hipError_t crt_launch_find_nearest_prim(const crt::PrimDev*, const void*, void*, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_render_prim(const crt::Scene*, const crt::PrimDev*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_check_reciprocals(unsigned long long*, hipStream_t);
 extern "C" hipError_t crt_launch_find_nearest_alt(int, const crt::Scene*, const crt::AltAccelDev*, const void*, void*, uint32_t, hipStream_t);
 
@@ -96,6 +104,7 @@ struct crt_ctx {
                   std::vector<uint64_t> pairBase, triBase; std::vector<uint32_t> nodesUsed, triCount; std::vector<char> geom; } flat;
     char* hStage[2] = {nullptr, nullptr}; size_t stageBytes[2] = {0, 0}; hipEvent_t stageCopied[2] = {nullptr, nullptr}; int stageFlip = 0;
     hipEvent_t sceneReady = nullptr;      // recorded behind the last in-place scene update; render launches wait for it on their stream
+    bool havePrim = false; crt::PrimDev prim{}; uint32_t* dPrimTex = nullptr;       // crt_upload_primitive_scene: PrimitiveScene instead of a triangle scene
     int renderAccel = 0;                  // crt_set_render_accel: 0 = the scene's BVH / TLAS, CRT_ACCEL_KDTREE / CRT_ACCEL_GRID = Sample and Trace go through that structure
     crt::AltAccelDev alt{}; bool haveKd = false, haveGrid = false; std::vector<void*> altAllocs[2]; void* altTris = nullptr; uint32_t altTriCount = 0;   // KD-tree [0] / grid [1] buffers
     void* dQueryRays = nullptr; void* dQueryHits = nullptr; size_t queryCap = 0;      // crt_find_nearest staging (rays)
@@ -155,6 +164,8 @@ struct crt_ctx {
     {
         for (void* p : sceneAllocs) (void)hipFree(p);
         sceneAllocs.clear(); haveScene = false;
+        if (dPrimTex) { (void)hipFree(dPrimTex); dPrimTex = nullptr; }
+        havePrim = false;
         freeAlt();                        // the alternative accelerators index the scene's triangles
     }
 };
@@ -1255,7 +1266,7 @@ static int probe_tile_costs(crt_ctx* c, hipStream_t st)
 int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
 {
     if (!c) return CRT_ERR_INVALID;
-    if (!c->haveScene) return c->fail(CRT_ERR_STATE, "crt_render before crt_upload_scene");
+    if (!c->haveScene && !c->havePrim) return c->fail(CRT_ERR_STATE, "crt_render before crt_upload_scene");
     if (passes < 1 || passes > 4) return c->fail(CRT_ERR_INVALID, "passes must be 1..4 (the reference's UI range, renderer.cpp:178)");
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (c->tileCount == 0 || frames == 0) return CRT_OK;
@@ -1271,8 +1282,8 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
     uint32_t maxF = 0;
     { int r = ensure_pool(c, frames, passes, &maxF); if (r) return r; }
     const size_t windowBytes = window_bytes(c, passes);
-    if (c->renderAccel != 0) {
-        // Renderer::Sample through FileScene's KD-tree / grid (crt_set_render_accel): the sequential form — one wavefront per (tile, window), lane = frame — on the
+    if (c->renderAccel != 0 || c->havePrim) {
+        // Renderer::Sample through FileScene's KD-tree / grid, or over the PrimitiveScene (crt_set_render_accel): the sequential form — one wavefront per (tile, window), lane = frame — on the
         // main stream, followed by the ordered accumulate; no planning, no latency mode (the BASELINE configurations are BVH-SAH; this path exists for parity
         // with the reference's shipped FileScene, which traces through its KD-tree: file_scene.h:10-12)
         for (uint32_t f0 = 0; f0 < frames; f0 += maxF) {
@@ -1281,7 +1292,8 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
             if ((r = take_region(c, (size_t)((nf + 63u) / 64u) * windowBytes, c->stream, &off))) return r;
             if (c->sceneReady) HIPCK(c, hipStreamWaitEvent(c->stream, c->sceneReady, 0));
             void* slab = c->pool + off;
-            HIPCK(c, crt_launch_render_alt(c->renderAccel, &c->hScene, &c->alt, slab, c->dCounters, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->stream));
+            if (c->havePrim) HIPCK(c, crt_launch_render_prim(&c->hScene, &c->prim, slab, c->dCounters, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->stream));
+            else HIPCK(c, crt_launch_render_alt(c->renderAccel, &c->hScene, &c->alt, slab, c->dCounters, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, spp_first + f0 * passes, nf, passes, c->stream));
             HIPCK(c, crt_launch_accumulate(slab, c->dAcc, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX, (uint32_t)c->cfg.width, nf, passes, c->stream));
             crt_ctx::Region reg; reg.off = off; reg.bytes = (size_t)((nf + 63u) / 64u) * windowBytes;
             if (c->freeEvents.empty()) HIPCK(c, hipEventCreateWithFlags(&reg.freed, hipEventDisableTiming));
@@ -1506,7 +1518,7 @@ int crt_whitted_tick(crt_ctx* c, uint32_t* hostPixels)
 int crt_find_nearest(crt_ctx* c, const crt_ray* rays, crt_hit* hits, size_t n)
 {
     if (!c || (n && (!rays || !hits))) return CRT_ERR_INVALID;
-    if (!c->haveScene) return c->fail(CRT_ERR_STATE, "crt_find_nearest before crt_upload_scene");
+    if (!c->haveScene && !c->havePrim) return c->fail(CRT_ERR_STATE, "crt_find_nearest before crt_upload_scene");
     if (n == 0) return CRT_OK;
     if (n > 0x7fffffffull) return c->fail(CRT_ERR_UNSUPPORTED, "at most 2^31-1 rays per call");
     HIPCK(c, hipSetDevice(c->cfg.device));
@@ -1522,7 +1534,8 @@ int crt_find_nearest(crt_ctx* c, const crt_ray* rays, crt_hit* hits, size_t n)
     }
     void *dR = c->dQueryRays, *dH = c->dQueryHits;
     HIPCK(c, hipMemcpyAsync(dR, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, crt_launch_find_nearest(&c->hScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->stream));
+    if (c->havePrim) HIPCK(c, crt_launch_find_nearest_prim(&c->prim, dR, dH, (uint32_t)n, c->stream));
+    else HIPCK(c, crt_launch_find_nearest(&c->hScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->stream));
     HIPCK(c, hipMemcpyAsync(hits, dH, n * sizeof(crt_hit), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
@@ -1599,6 +1612,31 @@ int crt_upload_alt_accel(crt_ctx* c, const crt_alt_accel* a)
         for (int k = 0; k < 3; k++) { c->alt.res[k] = a->gridResolution[k]; c->alt.cell[k] = a->gridCellSize[k]; c->alt.lo[k] = a->gridMin[k]; c->alt.hi[k] = a->gridMax[k]; }
         c->haveGrid = true;
     }
+    return CRT_OK;
+}
+
+int crt_upload_primitive_scene(crt_ctx* c, const crt_primitive_scene* ps)
+{
+    if (!c || !ps) return CRT_ERR_INVALID;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    for (const crt_texture* t : {&ps->red, &ps->blue})
+        if (t->pixels && (t->width != 512 || t->height != 512)) return c->fail(CRT_ERR_INVALID, "PrimitiveScene wall images are 512 x 512 (Plane::GetAlbedo masks the texel coordinates with 511)");
+    for (auto st : c->streams) HIPCK(c, hipStreamSynchronize(st));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->freeScene();
+    crt::PrimDev& p = c->prim; p = crt::PrimDev{};
+    memcpy(p.quadInvT, ps->quadInvT, 48); p.quadNrm[0] = -ps->quadT[1]; p.quadNrm[1] = -ps->quadT[5]; p.quadNrm[2] = -ps->quadT[9]; p.quadSize = ps->quadSize;   // Quad::GetNormal, primitives.h:363-367
+    memcpy(p.spherePos, ps->spherePos, 12);
+    memcpy(p.cubeInvM, ps->cubeInvM, 48); memcpy(p.cubeM, ps->cubeM, 48); memcpy(p.cubeMin, ps->cubeMin, 12); memcpy(p.cubeMax, ps->cubeMax, 12);
+    memcpy(p.torusInvT, ps->torusInvT, 48); memcpy(p.torusT, ps->torusT, 48); p.rt2 = ps->torusRt2; p.rc2 = ps->torusRc2; p.r2 = ps->torusR2;
+    memcpy(p.refl, ps->reflectivity, 44); memcpy(p.refr, ps->refractivity, 44); memcpy(p.absorb, ps->absorption, 132);
+    HIPCK(c, hipMalloc((void**)&c->dPrimTex, 2u * 512u * 512u * 4u));
+    HIPCK(c, hipMemsetAsync(c->dPrimTex, 0, 2u * 512u * 512u * 4u, c->stream));
+    if (ps->red.pixels) HIPCK(c, hipMemcpyAsync(c->dPrimTex, ps->red.pixels, 512u * 512u * 4u, hipMemcpyHostToDevice, c->stream));
+    if (ps->blue.pixels) HIPCK(c, hipMemcpyAsync(c->dPrimTex + 512u * 512u, ps->blue.pixels, 512u * 512u * 4u, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    p.red = c->dPrimTex; p.blue = c->dPrimTex + 512u * 512u;
+    c->havePrim = true; c->orderDirty = false;
     return CRT_OK;
 }
 

@@ -19,6 +19,7 @@ struct crt_host_renderer { Renderer* r = nullptr; };
 extern "C" {
 
 const char* crt_host_last_error(void) { return g_err.c_str(); }
+void crt_host_set_error(const char* msg) { g_err = msg ? msg : ""; }      // (other translation units of the host front: primitive_scene.cpp)
 
 int crt_host_scene_load(const char* xml, int kind, const char* base, crt_host_scene** out)
 {

@@ -214,6 +214,24 @@ int  crt_find_nearest_alt(crt_ctx* ctx, int kind, const crt_ray* rays, crt_hit* 
  * exactly 0 (kdtree.cpp:161-201).  The sequential form (one wavefront per tile and 64-frame window); reset by crt_upload_scene / crt_upload_alt_accel of the kind. */
 int  crt_set_render_accel(crt_ctx* ctx, int kind);
 
+/* ---- PrimitiveScene (second half): infra/scene/primitive_scene.cpp — the reference's hard-coded demo room (six walls, swinging light quad,
+ * bouncing mirror ball, "rounded corners" sphere, spinning glass cube, glass torus; template/primitives.h Sphere :31, Cube :187, Quad :321, Torus :380; the
+ * SPEEDTRIX / single-light configuration its headers select).  The binding passes the scene as its constructor + SetTime(t) leave it: the members below.
+ * After crt_upload_primitive_scene, crt_render (Renderer::Sample), crt_find_nearest (objIdx 0 .. 10, u = v = 0, triIdx = -1) and the accumulator entry points
+ * work on this scene (it replaces an uploaded triangle scene; crt_whitted_tick, crt_update_scene and the alternative accelerators do not apply).
+ * PARITY UNPINNED: checked bit for bit against the repo's oracle only (the reference files need MSVC); the torus' double-precision cos(acos(x) / 3) is a
+ * deterministic fdlibm-style evaluation on both sides, so its hit distances can differ from a Windows build of the reference in the last place. */
+typedef struct crt_primitive_scene {
+    float quadT[16], quadInvT[16]; float quadSize;             /* Quad quad: T, invT (FastInvertedTransformNoScale), size (= 0.5)            */
+    float spherePos[3];                                        /* Sphere sphere (r = 0.6): pos; sphere2 is constant (0, 2.5, -3.07), r = 8      */
+    float cubeMin[3], cubeMax[3], cubeM[16], cubeInvM[16];     /* Cube cube: b[0], b[1], M, invM                                               */
+    float torusT[16], torusInvT[16];                           /* Torus torus: T, invT (mat4::Inverted)                                        */
+    float torusRt2, torusRc2, torusR2;                         /*              rt2, rc2, r2                                                     */
+    float reflectivity[11], refractivity[11], absorption[11][3];   /* Material materials[11] (isLight: index 0; isAlbedoOverridden: 4, 5, 6)   */
+    crt_texture red, blue;                                     /* Plane::GetAlbedo's "../assets/red.png" / "blue.png" as Surface loads them (0x00RRGGBB, 512 x 512); pixels may be NULL */
+} crt_primitive_scene;
+int  crt_upload_primitive_scene(crt_ctx* ctx, const crt_primitive_scene* scene);
+
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
 int  crt_get_counters(crt_ctx* ctx, crt_counters* out);        /* cumulative since create / crt_reset_counters       */
 int  crt_reset_counters(crt_ctx* ctx);

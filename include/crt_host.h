@@ -75,6 +75,14 @@ const float* crt_host_renderer_accumulator(crt_host_renderer* r);               
 const uint32_t* crt_host_renderer_screen(crt_host_renderer* r);                     /* screen->pixels                */
 crt_ctx* crt_host_renderer_ctx(crt_host_renderer* r);
 
+/* PrimitiveScene (infra/scene/primitive_scene.cpp): constructor (assetsDir holds red.png / blue.png; NULL or "": black walls), SetTime, the description the
+ * C ABI takes (crt_primitive_scene; the image pointers stay owned by the handle), upload = crt_upload_primitive_scene */
+int  crt_host_primitive_scene_create(const char* assetsDir, void** out);
+void crt_host_primitive_scene_free(void* scene);
+int  crt_host_primitive_scene_set_time(void* scene, float t);
+int  crt_host_primitive_scene_desc(void* scene, crt_primitive_scene* out);
+int  crt_host_primitive_scene_upload(void* scene, crt_ctx* ctx);
+
 /* asset parsers */
 int  crt_host_obj_load(const char* path, uint32_t* corners, float** pos, float** nrm, float** uv);   /* arrays owned by the library until crt_host_free */
 int  crt_host_image_load(const char* path, int* width, int* height, uint32_t** pixels);

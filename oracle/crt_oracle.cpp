@@ -627,6 +627,259 @@ struct QuadPrim { // template/primitives.h:321-375
     V3 normal() const { return v3(-T.c[1], -T.c[5], -T.c[9]); }
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// PrimitiveScene (second half): infra/scene/primitive_scene.cpp + template/primitives.h (Sphere :31, Cube :187, Quad :321, Torus :380), the
+// SPEEDTRIX / single-light configuration the headers select.  PARITY UNPINNED: neither file compiles with the compilers of this image (MSVC-only __m128 member
+// access) and the reference holds no fixture of this scene.  The torus solves its quartic in double precision with cos(acos(x) / 3): the reference takes both from
+// the C runtime (unspecified to the bit); here they are det_acos / det_cos below — plain IEEE double + - * / sqrt, the published fdlibm algorithms (e_acos.c,
+// k_cos.c, k_sin.c, one-step e_rem_pio2.c) — so that this file and the HIP kernels (render_prim.hip) agree bit for bit.
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t hi_word(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)(u >> 32); }
+static inline double with_words(uint32_t hi, uint32_t lo) { uint64_t u = ((uint64_t)hi << 32) | lo; double d; memcpy(&d, &u, 8); return d; }
+static double det_acos(double x)
+{
+    const double one = 1.0, pi = 3.14159265358979311600e+00, pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+        pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+        pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05, qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+        qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+    const uint32_t hx = hi_word(x), ix = hx & 0x7fffffffu;
+    if (ix >= 0x3ff00000u) {                                  // |x| >= 1
+        if (x == 1.0) return 0.0;
+        if (x == -1.0) return pi + 2.0 * pio2_lo;
+        return (x - x) / (x - x);                             // NaN
+    }
+    if (ix < 0x3fe00000u) {                                   // |x| < 0.5
+        if (ix <= 0x3c600000u) return pio2_hi + pio2_lo;
+        const double z = x * x;
+        const double pp = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double r = pp / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    } else if (hx & 0x80000000u) {                            // x < -0.5
+        const double z = (one + x) * 0.5;
+        const double pp = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double sq = sqrt(z), r = pp / q, w = r * sq - pio2_lo;
+        return pi - 2.0 * (sq + w);
+    } else {                                                  // x > 0.5
+        const double z = (one - x) * 0.5, sq = sqrt(z);
+        const double df = with_words(hi_word(sq), 0u);
+        const double c = (z - df * df) / (sq + df);
+        const double pp = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double r = pp / q, w = r * sq + c;
+        return 2.0 * (df + w);
+    }
+}
+static double det_cos(double x)                               // 0 <= x < 3 pi / 4 is all the torus needs (acos(..) / 3 <= pi / 3); other inputs: NaN
+{
+    const double one = 1.0, C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+        C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11, S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+        S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10,
+        pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11, pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
+    const uint32_t ix = hi_word(x) & 0x7fffffffu;
+    if (!(x >= 0.0) || ix >= 0x4002d97cu) return (x - x) / (x - x);
+    if (ix <= 0x3fe921fbu) {                                  // |x| <= pi / 4: __kernel_cos(x, 0)
+        if (ix < 0x3e400000u) return one;
+        const double z = x * x;
+        const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+        if (ix < 0x3fd33333u) return one - (0.5 * z - (z * r - x * 0.0));
+        const double qx = (ix > 0x3fe90000u) ? 0.28125 : with_words(ix - 0x00200000u, 0u);
+        const double hz = 0.5 * z - qx, a = one - qx;
+        return a - (hz - (z * r - x * 0.0));
+    }
+    // pi / 4 < x < 3 pi / 4: x = pi / 2 + y, cos(x) = -sin(y) (__ieee754_rem_pio2 with n = 1, then __kernel_sin(y0, y1, 1))
+    double z = x - pio2_1, y0, y1;
+    if (ix != 0x3ff921fbu) { y0 = z - pio2_1t; y1 = (z - y0) - pio2_1t; }
+    else { z -= pio2_2; y0 = z - pio2_2t; y1 = (z - y0) - pio2_2t; }
+    const double zz = y0 * y0, v = zz * y0;
+    const double r = S2 + zz * (S3 + zz * (S4 + zz * (S5 + zz * S6)));
+    const double sn = y0 - ((zz * (0.5 * y1 - v * r) - y1) - v * S1);
+    return -sn;
+}
+static double cbrt_fast(double n)                             // Torus::cbrtFast, primitives.h:548-556 (float literals as written: 10.0f, 2.0f / 3.0f, 3.0f)
+{
+    double x1 = n / 10.0f, x2 = 1.0f; int turn = 0;
+    while (fabs(x1 - x2) > 0.00000001 && turn++ < 100) { x1 = x2; x2 = (2.0f / 3.0f * x1) + (n / (3.0f * x1 * x1)); }
+    return x2;
+}
+static M4 m4_inverted(const M4& m)                            // mat4::Inverted, tmplmath.h:769-813: the MESA cofactor formula, terms in the reference's order
+{
+    static const signed char T[16][6][4] = {
+        {{1, 5, 10, 15}, {-1, 5, 11, 14}, {-1, 9, 6, 15}, {1, 9, 7, 14}, {1, 13, 6, 11}, {-1, 13, 7, 10}}, {{-1, 1, 10, 15}, {1, 1, 11, 14}, {1, 9, 2, 15}, {-1, 9, 3, 14}, {-1, 13, 2, 11}, {1, 13, 3, 10}},
+        {{1, 1, 6, 15}, {-1, 1, 7, 14}, {-1, 5, 2, 15}, {1, 5, 3, 14}, {1, 13, 2, 7}, {-1, 13, 3, 6}}, {{-1, 1, 6, 11}, {1, 1, 7, 10}, {1, 5, 2, 11}, {-1, 5, 3, 10}, {-1, 9, 2, 7}, {1, 9, 3, 6}},
+        {{-1, 4, 10, 15}, {1, 4, 11, 14}, {1, 8, 6, 15}, {-1, 8, 7, 14}, {-1, 12, 6, 11}, {1, 12, 7, 10}}, {{1, 0, 10, 15}, {-1, 0, 11, 14}, {-1, 8, 2, 15}, {1, 8, 3, 14}, {1, 12, 2, 11}, {-1, 12, 3, 10}},
+        {{-1, 0, 6, 15}, {1, 0, 7, 14}, {1, 4, 2, 15}, {-1, 4, 3, 14}, {-1, 12, 2, 7}, {1, 12, 3, 6}}, {{1, 0, 6, 11}, {-1, 0, 7, 10}, {-1, 4, 2, 11}, {1, 4, 3, 10}, {1, 8, 2, 7}, {-1, 8, 3, 6}},
+        {{1, 4, 9, 15}, {-1, 4, 11, 13}, {-1, 8, 5, 15}, {1, 8, 7, 13}, {1, 12, 5, 11}, {-1, 12, 7, 9}}, {{-1, 0, 9, 15}, {1, 0, 11, 13}, {1, 8, 1, 15}, {-1, 8, 3, 13}, {-1, 12, 1, 11}, {1, 12, 3, 9}},
+        {{1, 0, 5, 15}, {-1, 0, 7, 13}, {-1, 4, 1, 15}, {1, 4, 3, 13}, {1, 12, 1, 7}, {-1, 12, 3, 5}}, {{-1, 0, 5, 11}, {1, 0, 7, 9}, {1, 4, 1, 11}, {-1, 4, 3, 9}, {-1, 8, 1, 7}, {1, 8, 3, 5}},
+        {{-1, 4, 9, 14}, {1, 4, 10, 13}, {1, 8, 5, 14}, {-1, 8, 6, 13}, {-1, 12, 5, 10}, {1, 12, 6, 9}}, {{1, 0, 9, 14}, {-1, 0, 10, 13}, {-1, 8, 1, 14}, {1, 8, 2, 13}, {1, 12, 1, 10}, {-1, 12, 2, 9}},
+        {{-1, 0, 5, 14}, {1, 0, 6, 13}, {1, 4, 1, 14}, {-1, 4, 2, 13}, {-1, 12, 1, 6}, {1, 12, 2, 5}}, {{1, 0, 5, 10}, {-1, 0, 6, 9}, {-1, 4, 1, 10}, {1, 4, 2, 9}, {1, 8, 1, 6}, {-1, 8, 2, 5}}};
+    float inv[16];
+    for (int i = 0; i < 16; i++) {
+        float acc = 0;
+        for (int k = 0; k < 6; k++) {
+            const float t = m.c[T[i][k][1]] * m.c[T[i][k][2]] * m.c[T[i][k][3]];
+            if (k == 0) acc = T[i][k][0] < 0 ? -t : t; else acc = T[i][k][0] < 0 ? acc - t : acc + t;
+        }
+        inv[i] = acc;
+    }
+    const float det = m.c[0] * inv[0] + m.c[1] * inv[4] + m.c[2] * inv[8] + m.c[3] * inv[12];
+    M4 r = m4_identity();
+    if (det != 0) { const float invdet = 1.0f / det; for (int i = 0; i < 16; i++) r.c[i] = inv[i] * invdet; }
+    return r;
+}
+
+struct PrimScene {
+    QuadPrim quad; V3 spherePos = v3(0); V3 cubeMin = v3(0), cubeMax = v3(0); M4 cubeM = m4_identity(), cubeInvM = m4_identity();
+    M4 torusT = m4_identity(), torusInvT = m4_identity(); float rt2 = 0, rc2 = 0, r2 = 0;
+    Tex red, blue;
+    Mat materials[11];
+    void construct()                                           // PrimitiveScene::PrimitiveScene, primitive_scene.cpp:4-42
+    {
+        quad.size = 1 * 0.5f; quad.objIdx = 0;
+        cubeMin = v3(0) - 0.5f * v3(1.15f); cubeMax = v3(0) + 0.5f * v3(1.15f);
+        const float a = 0.8f, b = 0.25f; rc2 = a * a; rt2 = b * b; r2 = (a + b) * (a + b);        // Torus(10, 0.8f, 0.25f)
+        torusT = m4_mul(m4_translate(v3(-0.25f, 0, 2)), m4_rotx(kPI / 4)); torusInvT = m4_inverted(torusT);
+        for (Mat& m : materials) m = Mat();
+        materials[0].isLight = true; materials[1].reflectivity = 1.0f; materials[3].refractivity = 1.0f; materials[3].absorption = v3(0.5f, 0, 0.5f);
+        materials[6].reflectivity = 0.3f; materials[10].refractivity = 1.0f;
+        set_time(0);
+    }
+    void set_time(float t)                                     // PrimitiveScene::SetTime, primitive_scene.cpp:44-68
+    {
+        M4 M1 = m4_mul(m4_mul(m4_translate(v3(0, 2.6f, 2)), m4_rotz(sinf(t * 0.6f) * 0.1f)), m4_translate(v3(0, -0.9f, 0)));
+        quad.T = M1; quad.invT = m4_fast_inverted_noscale(M1);
+        M4 M2base = m4_mul(m4_rotx(kPI / 4), m4_rotz(kPI / 4));
+        M4 M2 = m4_mul(m4_mul(m4_translate(v3(1.8f, 0, 2.5f)), m4_roty(t * 0.5f)), M2base);
+        cubeM = M2; cubeInvM = m4_fast_inverted_noscale(M2);
+        const float f = fmodf(t, 2.0f) - 1, tm = 1 - f * f;
+        spherePos = v3(-1.8f, -0.4f + tm, 1);
+    }
+    static bool is_overridden(int objIdx) { return objIdx >= 4 && objIdx <= 6; }      // Material(true): left wall, right wall, floor
+    void find_nearest(Ray& r) const                            // PrimitiveScene::FindNearest, primitive_scene.cpp:92-175 (SPEEDTRIX branches)
+    {
+        {   // room walls: per axis the plane the ray looks at (D >= 0: the far one), d = 0 - (O + x) * rD, first unconditional then strict <
+            const float xmin[3] = {3, 1, 3}, xmax[3] = {-2.99f, -2, -3.99f};
+            float t3[3]; int id3[3];
+            for (int a = 0; a < 3; a++) {
+                const bool sel = comp(r.D, a) >= 0;
+                const float x = sel ? xmax[a] : xmin[a];
+                id3[a] = sel ? 5 + 2 * a : 4 + 2 * a;
+                const float d = 0.0f - ((comp(r.O, a) + x) * comp(r.rD, a));
+                t3[a] = (d <= 0.0f) ? 1e34f : d;
+            }
+            r.t = t3[0]; r.objIdx = id3[0];
+            if (t3[1] < r.t) { r.t = t3[1]; r.objIdx = id3[1]; }
+            if (t3[2] < r.t) { r.t = t3[2]; r.objIdx = id3[2]; }
+        }
+        quad.intersect(r);
+        {   // bouncing ball (r = 0.6): front intersection only
+            const V3 oc = r.O - spherePos;
+            const float b = dot(oc, r.D);
+            const float d = b * b - (dot(oc, oc) - 0.36f);
+            if (d > 0) { const float t = -b - sqrtf(d); if (t < r.t && t > 0) { r.t = t; r.objIdx = 1; } }
+        }
+        {   // rounded corners (r = 8, seen from inside): back intersection only
+            const V3 oc = r.O - v3(0, 2.5f, -3.07f);
+            const float b = dot(oc, r.D);
+            const float d = b * b - (dot(oc, oc) - 64.0f);
+            if (d > 0) { const float t = sqrtf(d) - b; if (t < r.t && t > 0) { r.t = t; r.objIdx = 2; } }
+        }
+        {   // Cube::Intersect, primitives.h:200-225 (SSE summation order: (x + y) + (z + w) for O, (x + y) + z for D; _mm_min_ps / _mm_max_ps operand order)
+            const V3 O = transform_position_sse(r.O, cubeInvM), D = transform_vector_sse(r.D, cubeInvM);
+            const V3 rd = v3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+            const V3 t1 = (cubeMin - O) * rd, t2 = (cubeMax - O) * rd;
+            const V3 vmaxv = v3(mm_max(t1.x, t2.x), mm_max(t1.y, t2.y), mm_max(t1.z, t2.z)), vminv = v3(mm_min(t1.x, t2.x), mm_min(t1.y, t2.y), mm_min(t1.z, t2.z));
+            const float tmax = smin_(vmaxv.x, smin_(vmaxv.y, vmaxv.z)), tmin = smax_(vminv.x, smax_(vminv.y, vminv.z));
+            if (tmin < tmax) { if (tmin > 0) { if (tmin < r.t) { r.t = tmin; r.objIdx = 3; } } else if (tmax > 0) { if (tmax < r.t) { r.t = tmax; r.objIdx = 3; } } }
+        }
+        torus_intersect(r);
+    }
+    void torus_intersect(Ray& ray) const                       // Torus::Intersect, primitives.h:386-453 (double precision)
+    {
+        const V3 O = transform_position_sse(ray.O, torusInvT), D = transform_vector_sse(ray.D, torusInvT);
+        double po = 1, m = dot(O, O), k3 = dot(O, D), k32 = k3 * k3;
+        const double v = k32 - m + r2;
+        if (v < 0) return;
+        double k = (m - rt2 - rc2) * 0.5, k2 = k32 + rc2 * D.z * D.z + k;
+        double k1 = k * k3 + rc2 * O.z * D.z, k0 = k * k + rc2 * O.z * O.z - rc2 * rt2;
+        if (fabs(k3 * (k32 - k2) + k1) < 0.0001) {
+            const double tmp = k1; k1 = k3; k3 = tmp;
+            po = -1; k0 = 1 / k0; k1 = k1 * k0; k2 = k2 * k0; k3 = k3 * k0; k32 = k3 * k3;
+        }
+        double c2 = 2 * k2 - 3 * k32, c1 = k3 * (k32 - k2) + k1;
+        double c0 = k3 * (k3 * (-3 * k32 + 4 * k2) - 8 * k1) + 4 * k0;
+        c2 *= 0.33333333333; c1 *= 2; c0 *= 0.33333333333;
+        const double Q = c2 * c2 + c0, R = 3 * c0 * c2 - c2 * c2 * c2 - c1 * c1;
+        double h = R * R - Q * Q * Q, z;
+        if (h < 0) { const double sQ = sqrt(Q); z = 2 * sQ * det_cos(det_acos(R / (sQ * Q)) * 0.33333333333); }
+        else { const double sQ = cbrt_fast(sqrt(h) + fabs(R)); z = copysign(fabs(sQ + Q / sQ), R); }
+        z = c2 - z;
+        double d1 = z - 3 * c2, d2 = z * z - 3 * c0;
+        if (fabs(d1) < 1.0e-8) { if (d2 < 0) return; d2 = sqrt(d2); }
+        else { if (d1 < 0) return; d1 = sqrt(d1 * 0.5); d2 = c1 / d1; }
+        double t = 1e20;
+        h = d1 * d1 - z + d2;
+        if (h > 0) {
+            h = sqrt(h);
+            double t1 = -d1 - h - k3, t2 = -d1 + h - k3;
+            t1 = (po < 0) ? 2 / t1 : t1; t2 = (po < 0) ? 2 / t2 : t2;
+            if (t1 > 0) t = t1;
+            if (t2 > 0) t = (t2 < t) ? t2 : t;
+        }
+        h = d1 * d1 - z - d2;
+        if (h > 0) {
+            h = sqrt(h);
+            double t1 = d1 - h - k3, t2 = d1 + h - k3;
+            t1 = (po < 0) ? 2 / t1 : t1; t2 = (po < 0) ? 2 / t2 : t2;
+            if (t1 > 0) t = (t1 < t) ? t1 : t;
+            if (t2 > 0) t = (t2 < t) ? t2 : t;
+        }
+        const float ft = (float)t;
+        if (ft > 0 && ft < ray.t) { ray.t = ft; ray.objIdx = 10; }
+    }
+    V3 normal(int objIdx, V3 I) const                          // PrimitiveScene::GetHitInfo, primitive_scene.cpp:202-236 (before the flip towards the ray)
+    {
+        switch (objIdx) {
+        case 0: return quad.normal();
+        case 1: return (I - spherePos) * (1 / 0.6f);
+        case 2: return (I - v3(0, 2.5f, -3.07f)) * (1 / 8.0f);
+        case 3: {                                              // Cube::GetNormal, primitives.h:276-291
+            const V3 o = transform_position(I, cubeInvM);
+            V3 N = v3(-1, 0, 0);
+            const float d0 = fabsf(o.x - cubeMin.x), d1 = fabsf(o.x - cubeMax.x), d2 = fabsf(o.y - cubeMin.y), d3 = fabsf(o.y - cubeMax.y), d4 = fabsf(o.z - cubeMin.z), d5 = fabsf(o.z - cubeMax.z);
+            float minDist = d0;
+            if (d1 < minDist) { minDist = d1; N.x = 1; }
+            if (d2 < minDist) { minDist = d2; N = v3(0, -1, 0); }
+            if (d3 < minDist) { minDist = d3; N = v3(0, 1, 0); }
+            if (d4 < minDist) { minDist = d4; N = v3(0, 0, -1); }
+            if (d5 < minDist) { minDist = d5; N = v3(0, 0, 1); }
+            return transform_vector(N, cubeM);
+        }
+        case 10: {                                             // Torus::GetNormal, primitives.h:525-530
+            const V3 L = transform_position(I, torusInvT);
+            const V3 N = normalize(L * (v3(dot(L, L) - rt2) - rc2 * v3(1, 1, -1)));
+            return transform_vector(N, torusT);
+        }
+        default: { V3 N = v3(0); const float s = 1 - 2 * (float)(objIdx & 1); const int a = (objIdx - 4) / 2; if (a == 0) N.x = s; else if (a == 1) N.y = s; else N.z = s; return N; }
+        }
+    }
+    V3 albedo_override(int objIdx, V3 I) const                 // PrimitiveScene::GetAlbedo -> Plane::GetAlbedo, primitives.h:134-172, for the planes whose material overrides
+    {
+        if (objIdx == 6) {                                     // floor, N.y == 1: checkerboard
+            int ix = (int)(I.x * 2 + 96.01f), iz = (int)(I.z * 2 + 96.01f);
+            if (ix == 98 && iz == 98) { ix = (int)(I.x * 32.01f); iz = (int)(I.z * 32.01f); }
+            if (ix == 94 && iz == 98) { ix = (int)(I.x * 64.01f); iz = (int)(I.z * 64.01f); }
+            return v3(((ix + iz) & 1) ? 1 : 0.3f);
+        }
+        const Tex& tx = (objIdx == 4) ? red : blue;            // N.x == 1: red.png, N.x == -1: blue.png (512 x 512)
+        const int ix = (int)((I.z - 4) * (512.0f / 7)), iy = (int)((2 - I.y) * (512.0f / 3));
+        const uint32_t px = tx.px.empty() ? 0u : tx.px[(size_t)(ix & 511) + (size_t)(iy & 511) * 512];
+        return v3((float)((px >> 16) & 255), (float)((px >> 8) & 255), (float)(px & 255)) * (1.0f / 255.0f);
+    }
+};
+
 struct ObjDesc {
     std::vector<float> pos, nrm, uv; int nCorners = 0;
     V3 position, rotation, scale; int matIdx = 0;
@@ -653,6 +906,7 @@ struct orc_ctx {
     bool built = false;
     Mat primMat[2];
     PlanePrim floor; QuadPrim light;
+    PrimScene prim;                     // kind 2: PrimitiveScene (the scene IS its eleven hard-coded primitives; no BVH, no XML)
     std::vector<Bvh*> bvhs;            // kind 0: one; kind 1: one per object
     std::vector<int> objMat;           // FileScene: models[objIdx-2]->matIdx
     Tlas tlas;
@@ -677,9 +931,10 @@ struct orc_ctx {
         if (kind == 0 && accel != 0) accelFn(accelH, r);
         else if (kind == 0) bvhs[0]->traverse(r, cn); else tlas.traverse(r, cn);
     }
-    void find_nearest(Ray& r, Counters& cn) const // file_scene.cpp:170-175, tlas_file_scene.cpp:201-206
+    void find_nearest(Ray& r, Counters& cn) const // file_scene.cpp:170-175, tlas_file_scene.cpp:201-206; primitive_scene.cpp:92-175
     {
         cn.rays++;
+        if (kind == 2) { prim.find_nearest(r); return; }
         light.intersect(r);
         floor.intersect(r);
         accel_intersect(r, cn);
@@ -687,6 +942,7 @@ struct orc_ctx {
     }
     V3 sky_color(const Ray& r) const // file_scene.cpp:142-154
     {
+        if (kind == 2) return v3(0);                                         // PrimitiveScene::GetSkyColor
         float phi = det_atan2f(-r.D.z, r.D.x) + kPI;
         float theta = det_acosf(-r.D.y);
         float u = phi * kINV2PI, v = theta * kINVPI;
@@ -695,7 +951,8 @@ struct orc_ctx {
     HitInfo hit_info(const Ray& r, V3 I) const // file_scene.cpp:189-214, tlas_file_scene.cpp:220-260
     {
         HitInfo h; h.N = v3(0); h.uv.x = 0; h.uv.y = 0; h.mat = nullptr;
-        if (r.objIdx == 0) { h.N = light.normal(); h.mat = &primMat[0]; }
+        if (kind == 2) { h.N = prim.normal(r.objIdx, I); h.mat = &prim.materials[r.objIdx]; }
+        else if (r.objIdx == 0) { h.N = light.normal(); h.mat = &primMat[0]; }
         else if (r.objIdx == 1) { h.N = floor.N; h.uv = floor.uv(I); h.mat = &primMat[1]; }
         else {
             const Bvh* b = (kind == 0) ? bvhs[0] : tlas.blas[r.objIdx - 2];
@@ -733,7 +990,7 @@ struct orc_ctx {
         V3 I = ray.O + ray.t * ray.D;
         HitInfo hi = hit_info(ray, I);
         V3 N = hi.N;
-        V3 albedo = hi.mat->get_albedo(hi.uv);
+        V3 albedo = (kind == 2 && PrimScene::is_overridden(ray.objIdx)) ? prim.albedo_override(ray.objIdx, I) : hi.mat->get_albedo(hi.uv);   // renderer.cpp:61 (isAlbedoOverridden)
         if (hi.mat->isLight) return v3(24, 24, 22);
         float reflectivity = hi.mat->reflectivity, refractivity = hi.mat->refractivity;
         V3 medium = v3(1);
@@ -846,7 +1103,27 @@ static const float kDeg2Rad = (kPI * 2) / 360.0f; // infra/helper.h:152
 
 extern "C" {
 
-orc_ctx* orc_create(int kind) { orc_ctx* c = new orc_ctx(); c->kind = kind ? 1 : 0; return c; }
+orc_ctx* orc_create(int kind) { orc_ctx* c = new orc_ctx(); c->kind = kind == 2 ? 2 : (kind ? 1 : 0); if (c->kind == 2) { c->prim.construct(); c->built = true; } return c; }
+// PrimitiveScene (kind 2): the two wall images (red.png / blue.png as Surface loads them: 0x00RRGGBB, 512 x 512; NULL = black) and the animation time
+int orc_prim_setup(orc_ctx* c, const uint32_t* red, const uint32_t* blue)
+{
+    if (!c || c->kind != 2) return -1;
+    if (red) { c->prim.red.px.assign(red, red + 512 * 512); c->prim.red.w = c->prim.red.h = 512; }
+    if (blue) { c->prim.blue.px.assign(blue, blue + 512 * 512); c->prim.blue.w = c->prim.blue.h = 512; }
+    return 0;
+}
+int orc_prim_set_time(orc_ctx* c, float t) { if (!c || c->kind != 2) return -1; c->prim.set_time(t); return 0; }
+// 16 x 5 matrices (quad T, invT, cube M, invM, torus T... invT) + sphere position + torus radii: what a host front must reproduce
+int orc_prim_state(orc_ctx* c, float* out)
+{
+    if (!c || c->kind != 2) return -1;
+    const M4* ms[6] = {&c->prim.quad.T, &c->prim.quad.invT, &c->prim.cubeM, &c->prim.cubeInvM, &c->prim.torusT, &c->prim.torusInvT};
+    for (int k = 0; k < 6; k++) memcpy(out + 16 * k, ms[k]->c, 64);
+    st3(out + 96, c->prim.spherePos); out[99] = c->prim.rt2; out[100] = c->prim.rc2; out[101] = c->prim.r2; st3(out + 102, c->prim.cubeMin); st3(out + 105, c->prim.cubeMax);
+    return 0;
+}
+double orc_det_acos(double x) { return det_acos(x); }
+double orc_det_cos(double x) { return det_cos(x); }
 void orc_destroy(orc_ctx* c) { delete c; }
 const char* orc_last_error(orc_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 

@@ -121,6 +121,12 @@ void orc_grid_intersect(void* h, const float* O, const float* D, uint32_t n, orc
 void orc_grid_free(void* h);
 /* Sample / Trace through the KD-tree (1) or grid (2) of a FileScene instead of its BVH (file_scene.h:10-12): h = the structure built over the scene's triangles */
 int orc_set_render_accel(orc_ctx*, int kind, void* h);
+/* PrimitiveScene: orc_create(2); the wall images; animation time; state dump (6 matrices, sphere position, torus radii, cube box: 108 floats) */
+int orc_prim_setup(orc_ctx*, const uint32_t* red512, const uint32_t* blue512);
+int orc_prim_set_time(orc_ctx*, float t);
+int orc_prim_state(orc_ctx*, float* out108);
+double orc_det_acos(double x);
+double orc_det_cos(double x);
 void orc_math_probe(const float* in12, uint32_t n, float* out120);
 uint32_t orc_vertex_dedup(const float* v8, uint32_t n, uint32_t* idx, float* unique8);
 float orc_expf(float x);

@@ -604,6 +604,40 @@ class AltAccel:
             getattr(self.L, self.p + "_free")(self.h); self.h = None
 
 
+def primitive_scene(assets_dir=None, t=0.0):
+    """the oracle's PrimitiveScene (infra/scene/primitive_scene.cpp): orc_create(2) + the wall images (red.png / blue.png read by the oracle-side PNG reader) + SetTime(t)"""
+    o = Oracle(2)
+    red = blue = None
+    if assets_dir:
+        red = np.ascontiguousarray(pack_rgb(read_image(os.path.join(assets_dir, "red.png"))), np.uint32)
+        blue = np.ascontiguousarray(pack_rgb(read_image(os.path.join(assets_dir, "blue.png"))), np.uint32)
+        assert red.shape == (512, 512) and blue.shape == (512, 512)
+    if o.L.orc_prim_setup(o.h, None if red is None else _fp(red), None if blue is None else _fp(blue)) != 0:
+        raise RuntimeError("orc_prim_setup refused")
+    o._prim_keep = (red, blue)
+    o.L.orc_prim_set_time(o.h, C.c_float(t))
+    return o
+
+
+def prim_set_time(o, t):
+    if o.L.orc_prim_set_time(o.h, C.c_float(t)) != 0:
+        raise RuntimeError("orc_prim_set_time refused")
+
+
+def prim_state(o):
+    out = np.zeros(108, np.float32)
+    if o.L.orc_prim_state(o.h, _fp(out)) != 0:
+        raise RuntimeError("orc_prim_state refused")
+    return out
+
+
+def det_acos_cos():
+    L = lib()
+    L.orc_det_acos.restype = C.c_double; L.orc_det_acos.argtypes = [C.c_double]
+    L.orc_det_cos.restype = C.c_double; L.orc_det_cos.argtypes = [C.c_double]
+    return L.orc_det_acos, L.orc_det_cos
+
+
 def set_render_accel(scene, accel):
     """scene: an oracle scene (load_scene); accel: None (BVH again) or an AltAccel of the oracle built over scene.bvh(0)["tris"] — Sample / Trace then go through it"""
     L = lib()

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(crt):
     for sym in declared:
         assert hasattr(lib, sym), "include/*.h declares %s but libcrt_amd.so does not export it" % sym
     assert set(crt.ABI_SYMBOLS + crt.HOST_SYMBOLS) == set(declared)
-    assert lib.crt_abi_version() == 2
+    assert lib.crt_abi_version() == 3
 
 
 def test_record_layouts(crt):
@@ -291,3 +291,21 @@ def test_latency_tuner_step_is_monotone_and_valid(crt):
             assert np.all(np.diff(out[m][o].astype(np.int32)) <= 0)
     bad = np.array([3], np.uint8)
     assert L.crt_debug_next_lanes(bad.ctypes.data, cost.ctypes.data, 1, 1.0, np.zeros(1, np.uint8).ctypes.data) != 0
+
+
+def test_primitive_scene_host_front_matches_the_oracle_and_det_trig_is_accurate(crt, orc):
+    """PrimitiveScene's constructor + SetTime on the host front (csrc/host/primitive_scene.cpp) against the oracle's restatement (parity unpinned: both by this repo),
+    and the deterministic double-precision acos / cos both the oracle and the HIP kernel use for the torus against libm (<= 1 ulp)."""
+    import math
+    for t in (0.0, 0.37, 1.3, 12.5):
+        ps = crt.HostPrimitiveScene(None); ps.set_time(t)
+        o = orc.primitive_scene(None, t)
+        assert np.array_equal(ps.state().view(np.uint32), orc.prim_state(o).view(np.uint32)), t
+        ps.close()
+    acos, cos = orc.det_acos_cos()
+    rng = np.random.default_rng(3)
+    for x in rng.uniform(-1, 1, 20000):
+        assert abs(acos(x) - math.acos(x)) <= np.spacing(math.acos(x))
+    for x in rng.uniform(0, 2.35, 20000):
+        assert abs(cos(x) - math.cos(x)) <= np.spacing(abs(math.cos(x))) + 1e-17
+    assert acos(1.0) == 0.0 and acos(-1.0) == math.pi and cos(0.0) == 1.0

@@ -7,7 +7,7 @@ os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads it
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(REPO, "build", "variants")
 PKG = os.path.join(REPO, "cpu-ray-tracer_amd")
-SRC = ["csrc/device/kernels.hip", "csrc/device/render_pool.hip", "csrc/device/render_narrow.hip", "csrc/device/alt_accel.hip", "csrc/abi.cpp", "csrc/host/accel.cpp", "csrc/host/accel_alt.cpp", "csrc/host/loaders.cpp", "csrc/host/scene.cpp", "csrc/host/host_abi.cpp"]
+SRC = ["csrc/device/kernels.hip", "csrc/device/render_pool.hip", "csrc/device/render_narrow.hip", "csrc/device/render_prim.hip", "csrc/device/alt_accel.hip", "csrc/abi.cpp", "csrc/host/accel.cpp", "csrc/host/accel_alt.cpp", "csrc/host/loaders.cpp", "csrc/host/scene.cpp", "csrc/host/primitive_scene.cpp", "csrc/host/host_abi.cpp"]
 
 def fastbuild(specs):
     """variants that only differ in render_pool.hip: everything else is compiled once into build/obj/ and re-linked (seconds per variant)"""
