@@ -5,7 +5,7 @@
 // glass cube and the glass torus, in the SPEEDTRIX / single-light configuration its headers select.  No acceleration structure: every ray tests all eleven.
 //
 // PARITY UNPINNED.  Neither reference file compiles with this image's compilers (MSVC-only __m128 member access) and the reference holds no fixture of this scene; the
-// kernels are checked bit for bit against oracle/crt_oracle.cpp's restatement (PrimScene).  The torus solves its quartic in double precision with
+// kernels are checked bit for bit against the repo's CPU restatement of the same classes (tests/test_gpu_primitive_scene.py).  The torus solves its quartic in double precision with
 // cos(acos(x) / 3), which the reference takes from the C runtime (unspecified to the bit): both sides use the same fdlibm-style det_acos / det_cos below (plain
 // IEEE double + - * / sqrt), so oracle and kernel agree exactly; against a Windows build of the reference the torus' hit distances can differ in the last place.
 //
