@@ -133,6 +133,7 @@ struct crt_ctx {
     std::vector<uint32_t> jobOrder;
     uint32_t* dJobDesc = nullptr; uint32_t* hJobDesc = nullptr; uint32_t jobDescCap = 0, jobBlocks = 0, jobBlocksWide = 0, jobHead = 0; hipEvent_t jobDescReady = nullptr;
     uint32_t planWindows = 0, planFrames = 0; bool planPool = false, planValid = false;       // what the table on the device was planned for
+    double jobTrialMs[2] = {0, 0};          // this plan's shape timed [0] plain (cost-ordered, no table) and [1] planned: the faster one is kept (planner_prepare)
     std::vector<hipEvent_t> splitEvents;    // end events of the second kernel of split launches (recycled round-robin)
     size_t splitSeq = 0; uint32_t splitLaunches = 0;
     uint64_t poolMinWaves = 65000; // launches of fewer (tile, 64-frame window) pairs run render_tiles_kernel: see crt_render
@@ -1013,7 +1014,10 @@ static void harvest_tuning(crt_ctx* c)
         if (ev.mode < 0 || ev.seen) continue;
         if (hipEventQuery(ev.b) != hipSuccess) break;                   // launches complete in order per stream; stop at the first unfinished one
         float t = 0;
-        if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) { c->tuneMs[ev.mode] = c->tuneCount[ev.mode] ? (c->tuneMs[ev.mode] < t ? c->tuneMs[ev.mode] : t) : t; c->tuneCount[ev.mode]++; }
+        if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) {
+            if (ev.mode >= 100) { double& m = c->jobTrialMs[ev.mode - 100]; m = (m > 0 && m < t) ? m : t; }      // a job of the current plan's shape: plain (100) / planned (101)
+            else { c->tuneMs[ev.mode] = c->tuneCount[ev.mode] ? (c->tuneMs[ev.mode] < t ? c->tuneMs[ev.mode] : t) : t; c->tuneCount[ev.mode]++; }
+        }
         ev.seen = true;
     }
 }
@@ -1216,6 +1220,7 @@ static int install_job_plan(crt_ctx* c, uint32_t windows, uint32_t frames, bool 
     plan_job(c, windows, frames, pool, table, &head);
     c->jobBlocksWide = split_by_width(table);
     c->planValid = true; c->planWindows = windows; c->planFrames = frames; c->planPool = pool; c->jobHead = head; c->jobBlocks = (uint32_t)table.size();
+    c->jobTrialMs[0] = c->jobTrialMs[1] = 0;
     if (table.empty()) return 0;
     if (c->jobDescCap < table.size()) {
         if (c->dJobDesc) (void)hipFree(c->dJobDesc);
@@ -1231,6 +1236,153 @@ static int install_job_plan(crt_ctx* c, uint32_t windows, uint32_t frames, bool 
     HIPCK(c, hipMemcpyAsync(c->dJobDesc, c->hJobDesc, table.size() * 4, hipMemcpyHostToDevice, c->stream));      // main stream: behind every launch submitted so far
     HIPCK(c, hipEventRecord(c->jobDescReady, c->stream));
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// One render launch of crt_render = the three steps below, each owning its part of the context:
+//   tuner_prepare     single-window launches (8 .. 64 frames): the LATENCY tuner — owns lat*, cost*, dBlockDesc / nBlocks* (probe, stages, confirmation: next_block_table)
+//   planner_prepare   jobs (> 64 frames): tile-cost measurement and the PLANNER — owns jobCost*, rec*, plan*, dJobDesc / jobBlocks*, jobTrial* (plan_job, install_job_plan)
+//   launch_render_kernels   the LAUNCHER: render_pool_kernel / render_tiles_kernel / render_narrow_kernel on their streams, joined before the launch's end event
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+struct Launch {
+    hipStream_t st = nullptr; EventPair ev{}; void* slab = nullptr; uint32_t sppFirst = 0, nf = 0, passes = 1, windows = 1;
+    const uint32_t* blockDesc = nullptr; uint32_t nBlocks = 0, nBlocksWide = 0;      // the latency mode's table (single-window launch), or none
+    bool wantCost = false, wantJobCost = false, pool = false;
+    uint32_t head = 0, jobBlocks = 0, jobBlocksWide = 0; unsigned long long* jobClk = nullptr;      // a planned job: table blocks + first tile rank of the pool launch
+};
+
+static int next_block_table(crt_ctx* c);
+static int probe_tile_costs(crt_ctx* c, hipStream_t st);
+
+static int tuner_prepare(crt_ctx* c, Launch& L)
+{
+    int r;
+    // ... only when the GPU is idle at submission: a caller that queues launch after launch wants throughput, and narrow wavefronts buy latency with issue
+    // slots (56 queued single-window calls: 6.4 ms each with one wave per tile, 12.4 ms with the tuned table)
+    const bool gpuIdle = !c->lastRenderEnd || hipEventQuery(c->lastRenderEnd) == hipSuccess;
+    if (L.nf <= 64u && L.nf >= 8u && gpuIdle && !c->cfg.collectStats && c->tileCount <= 0x10000u && !hook("CRT_LAT_OFF")) {
+        if (c->costPending && hipEventQuery(c->costCopied) == hipSuccess) { c->costPending = false; harvest_tuning(c); if ((r = next_block_table(c))) return r; }
+        if (c->latStage == 0 && !c->latProbed && !c->latWarm && !c->costPending && L.nf == 64u && !hook("CRT_LAT_POLICY") && !hook("CRT_LAT_NO_PROBE")) { if ((r = probe_tile_costs(c, L.st))) return r; }
+        const int stage = c->latStage;
+        if (stage || c->latProbed) { L.blockDesc = c->dBlockDesc; L.nBlocks = c->nBlocks; L.nBlocksWide = c->nBlocksWide; HIPCK(c, hipStreamWaitEvent(L.st, c->descReady, 0)); }
+        L.wantCost = (!c->latDone && !c->costPending) || (c->latDone && hook("CRT_LAT_RECORD"));      // (the latter: diagnostics, crt_debug_tile_costs)
+        c->evRender.back().mode = c->latDone ? -1 : stage;
+        if (L.wantCost && !c->latDone) c->costStage = stage;
+    }
+    if (L.wantCost) {
+        if (!c->dTileCost) {
+            HIPCK(c, hipMalloc((void**)&c->dTileCost, (size_t)c->tileCount * 4));
+            HIPCK(c, hipHostMalloc((void**)&c->hTileCost, (size_t)c->tileCount * 4, hipHostMallocDefault));
+            HIPCK(c, hipEventCreateWithFlags(&c->costCopied, hipEventDisableTiming));
+        }
+        else HIPCK(c, hipStreamWaitEvent(L.st, c->costCopied, 0));          // behind an earlier measurement (possibly on another stream) that a camera change abandoned
+        HIPCK(c, hipMemsetAsync(c->dTileCost, 0, (size_t)c->tileCount * 4, L.st));
+    }
+    return 0;
+}
+
+static int planner_prepare(crt_ctx* c, Launch& L)
+{
+    int r;
+    // jobs: measure the tile costs once per camera / scene (first job launch), adopt them when they have arrived
+    if (L.nf > 64u && !c->cfg.collectStats) {
+        if (c->jobCostPending && hipEventQuery(c->jobCostCopied) == hipSuccess) { c->jobCostPending = false; if ((r = adopt_job_costs(c))) return r; HIPCK(c, hipStreamWaitEvent(L.st, c->orderReady, 0)); }
+        L.wantJobCost = !c->jobCostValid && !c->jobCostPending && L.nf >= 128u;       // (a pool launch records full 128-stream wavefronts only)
+        if (L.wantJobCost) {
+            if (!c->dJobCost) {
+                HIPCK(c, hipMalloc((void**)&c->dJobCost, job_cost_bytes(c)));
+                HIPCK(c, hipHostMalloc((void**)&c->hJobCost, job_cost_bytes(c), hipHostMallocDefault));
+                HIPCK(c, hipEventCreateWithFlags(&c->jobCostCopied, hipEventDisableTiming));
+            } else HIPCK(c, hipStreamWaitEvent(L.st, c->jobCostCopied, 0));      // behind an earlier measurement that a camera change abandoned
+            HIPCK(c, hipMemsetAsync(c->dJobCost, 0, job_cost_bytes(c), L.st));
+        }
+    }
+    // Which render kernel: the stream pool executes a third fewer instructions per sample, but its wavefronts own 128 streams for 64 lanes, so the most
+    // expensive tiles take about twice as long per wavefront; a launch that is not many times larger than the machine (4 096 - 5 120 wavefronts in
+    // flight) ends on those and is faster with one stream per lane.  Measured cross-over (tools/crossover.py, bench.py --steps): bunny 1280x720 at 17 - 20
+    // windows (20 windows: 81.0 ms pool, 87.6 ms tiles), TLAS scene at ~28, watch-tower 1920x1080 at 7 — 56 000 ... 100 000 (tile, window) pairs; the
+    // threshold sits at the low end of that range.
+    // With the tile costs known (most expensive first + split, see plan_job) the pool is never slower than one stream per lane from ~12 windows of 720p on
+    // (tools/split_probe.py: bunny 14 windows 57.8 against 59.6 ms, two-level scene 16 windows 79 against 94 ms, watch-tower 1080p 7 windows 155.6 against 161.1 ms).
+    const uint64_t minWaves = c->poolMinWaves != 65000u ? c->poolMinWaves : (c->jobCostValid ? 43000u : 65000u);
+    L.pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * L.windows >= minWaves && (c->poolMinWaves == 0 || L.nf > 64u);
+    if (L.nf > 64u && c->jobCostValid) {
+        if ((r = install_job_plan(c, L.windows, L.nf, L.pool))) return r;
+        // The plan is a MODEL (machine time within ~15 %): for a job shape that repeats (a progressive render) it is checked by measurement — the first launch of the
+        // shape runs planned, the second plain (same kernel choice, cost-ordered, no table), and whichever was faster is kept: "planned is never slower than the
+        // plain launch" holds by construction from the third launch on (tags 100 / 101 of the timing pairs, harvest_tuning).
+        int use = 1;                                                           // 1 planned, 0 plain
+        if (c->jobBlocks && !hook("CRT_PLAN_NO_TRIAL")) {
+            if (c->jobTrialMs[1] > 0 && c->jobTrialMs[0] > 0) use = c->jobTrialMs[1] <= c->jobTrialMs[0] ? 1 : 0;
+            else if (c->jobTrialMs[1] > 0 && c->jobTrialMs[0] == 0) use = 0;   // the planned launch has been timed: time the plain one
+            c->evRender.back().mode = 100 + use;
+        }
+        if (use) { L.head = c->jobHead; L.jobBlocks = c->jobBlocks; L.jobBlocksWide = c->jobBlocksWide; }
+    }
+    if (L.jobBlocks) HIPCK(c, hipStreamWaitEvent(L.st, c->jobDescReady, 0));
+    if (L.wantJobCost) {                                                 // what adopt_job_costs needs to know about the measuring launch
+        L.jobClk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->dJobCost) + job_cost_clk_offset(c));
+        c->recPool = L.pool; c->recWindows = L.windows;
+        c->recWaves = L.pool ? c->tileCount * ((L.nf + crt_pool_streams(L.nf) - 1u) / crt_pool_streams(L.nf)) : c->tileCount * L.windows;
+        c->recResident = L.pool ? 4096u : 5120u;                            // 4 / 5 wavefronts per SIMD (render_pool_kernel / render_tiles_kernel)
+    }
+    return 0;
+}
+
+static hipError_t launch_render_kernels(crt_ctx* c, const Launch& L)
+{
+    hipStream_t st = L.st;
+    hipError_t le = hipSuccess;
+    // a second kernel of the same launch on another stream: released by the launch's start event, joined before its end event
+    auto join = [&](hipStream_t other) -> hipError_t {
+        if (other == st) return hipSuccess;
+        hipError_t e = hipSuccess;
+        if (c->splitEvents.size() < 32) { hipEvent_t ne; e = hipEventCreateWithFlags(&ne, hipEventDisableTiming); if (e == hipSuccess) c->splitEvents.push_back(ne); }
+        if (e == hipSuccess) { hipEvent_t je = c->splitEvents[c->splitSeq++ % c->splitEvents.size()]; e = hipEventRecord(je, other); if (e == hipSuccess) e = hipStreamWaitEvent(st, je, 0); }
+        return e;
+    };
+    // a block table = [wide blocks: render_tiles_kernel on this launch's stream][blocks routed to render_narrow_kernel (split_by_width: none unless opted in) on the
+    // highest-priority stream, submitted first — they are the most expensive tiles' and the launch ends on them]
+    auto launch_table = [&](const uint32_t* desc, uint32_t nAll, uint32_t nWide, uint32_t* cost) -> hipError_t {
+        hipError_t e = hipSuccess;
+        hipStream_t sn = st;
+        if (nAll > nWide) {
+            if (!c->narrowStream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); e = hipStreamCreateWithPriority(&c->narrowStream, hipStreamNonBlocking, hi); if (e != hipSuccess) return e; }
+            sn = c->narrowStream;
+            e = hipStreamWaitEvent(sn, L.ev.a, 0);
+            if (e == hipSuccess) e = crt_launch_render_narrow(&c->hScene, L.slab, c->dCounters, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                                              L.sppFirst, L.nf, L.passes, c->ldsBytes, desc + nWide, nAll - nWide, cost, sn);
+        }
+        if (e == hipSuccess && nWide)
+            e = crt_launch_render(&c->hScene, L.slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                  L.sppFirst, L.nf, L.passes, c->ldsBytes, 0, desc, nWide, cost, 0u, nullptr, st);
+        if (e == hipSuccess) e = join(sn);                                 // (after both are submitted: the two kernels run side by side)
+        return e;
+    };
+    if (L.pool) {
+        void* scratch = (char*)L.slab + (size_t)L.windows * sample_bytes_per_window(c, L.passes);
+        hipStream_t st2 = st;
+        if (L.jobBlocks) {
+            // the expensive tiles first, through the block table, on this launch's stream; the pool for the rest on the next stream, released by the same start event
+            le = launch_table(c->dJobDesc, L.jobBlocks, L.jobBlocksWide, nullptr);
+            st2 = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
+            if (le == hipSuccess && st2 != st) le = hipStreamWaitEvent(st2, L.ev.a, 0);
+        }
+        if (le == hipSuccess)
+            le = crt_launch_render_pool(&c->hScene, L.slab, scratch, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                                        L.sppFirst, L.nf, L.passes, c->cfg.collectStats, L.jobBlocks ? L.head : 0u, L.wantJobCost ? c->dJobCost : nullptr, L.jobClk, st2);
+        if (L.jobBlocks && le == hipSuccess) le = join(st2);
+    } else if (L.jobBlocks) {
+        le = launch_table(c->dJobDesc, L.jobBlocks, L.jobBlocksWide, nullptr);
+    } else if (L.blockDesc && L.nBlocks) {
+        le = launch_table(L.blockDesc, L.nBlocks, L.nBlocksWide, L.wantCost ? c->dTileCost : nullptr);
+    } else {
+        le = crt_launch_render(&c->hScene, L.slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+                               L.sppFirst, L.nf, L.passes, c->ldsBytes, c->cfg.collectStats, nullptr, 0u,
+                               L.wantCost ? c->dTileCost : (L.wantJobCost ? c->dJobCost : nullptr), 0u, L.jobClk, st);
+    }
+    if (L.jobBlocks && le == hipSuccess) c->splitLaunches++;
+    return le;
 }
 
 // The first single-window launch after a camera / scene change used to run one wavefront per tile (34 ms for the 720p bunny) because nothing was known about the
@@ -1318,118 +1470,12 @@ int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
         // the pair is in the timing list from here on; any error exit before its end event is recorded takes it back (a half-recorded pair would make every
         // later crt_get_timing fail in hipEventElapsedTime)
         struct PairGuard { crt_ctx* c; bool armed; ~PairGuard() { if (armed && !c->evRender.empty()) { c->evPool.push_back(c->evRender.back()); c->evRender.pop_back(); } } } pairGuard{c, true};
-        // latency mode of a single-window launch (render_tiles_kernel): one wavefront per tile, or the current block table (see next_block_table)
-        const uint32_t* blockDesc = nullptr; uint32_t nBlocks = 0; bool wantCost = false;
-        // ... only when the GPU is idle at submission: a caller that queues launch after launch wants throughput, and narrow wavefronts buy latency with issue
-        // slots (56 queued single-window calls: 6.4 ms each with one wave per tile, 12.4 ms with the tuned table)
-        const bool gpuIdle = !c->lastRenderEnd || hipEventQuery(c->lastRenderEnd) == hipSuccess;
-        if (nf <= 64u && nf >= 8u && gpuIdle && !c->cfg.collectStats && c->tileCount <= 0x10000u && !hook("CRT_LAT_OFF")) {
-            if (c->costPending && hipEventQuery(c->costCopied) == hipSuccess) { c->costPending = false; harvest_tuning(c); if ((r = next_block_table(c))) return r; }
-            if (c->latStage == 0 && !c->latProbed && !c->latWarm && !c->costPending && nf == 64u && !hook("CRT_LAT_POLICY") && !hook("CRT_LAT_NO_PROBE")) { if ((r = probe_tile_costs(c, st))) return r; }
-            const int stage = c->latStage;
-            if (stage || c->latProbed) { blockDesc = c->dBlockDesc; nBlocks = c->nBlocks; HIPCK(c, hipStreamWaitEvent(st, c->descReady, 0)); }
-            wantCost = (!c->latDone && !c->costPending) || (c->latDone && hook("CRT_LAT_RECORD"));      // (the latter: diagnostics, crt_debug_tile_costs)
-            c->evRender.back().mode = c->latDone ? -1 : stage;
-            if (wantCost && !c->latDone) c->costStage = stage;
-        }
-        if (wantCost) {
-            if (!c->dTileCost) {
-                HIPCK(c, hipMalloc((void**)&c->dTileCost, (size_t)c->tileCount * 4));
-                HIPCK(c, hipHostMalloc((void**)&c->hTileCost, (size_t)c->tileCount * 4, hipHostMallocDefault));
-                HIPCK(c, hipEventCreateWithFlags(&c->costCopied, hipEventDisableTiming));
-            }
-            else HIPCK(c, hipStreamWaitEvent(st, c->costCopied, 0));          // behind an earlier measurement (possibly on another stream) that a camera change abandoned
-            HIPCK(c, hipMemsetAsync(c->dTileCost, 0, (size_t)c->tileCount * 4, st));
-        }
-        // jobs: measure the tile costs once per camera / scene (first job launch), adopt them when they have arrived
-        bool wantJobCost = false;
-        if (nf > 64u && !c->cfg.collectStats) {
-            if (c->jobCostPending && hipEventQuery(c->jobCostCopied) == hipSuccess) { c->jobCostPending = false; if ((r = adopt_job_costs(c))) return r; HIPCK(c, hipStreamWaitEvent(st, c->orderReady, 0)); }
-            wantJobCost = !c->jobCostValid && !c->jobCostPending && nf >= 128u;       // (a pool launch records full 128-stream wavefronts only)
-            if (wantJobCost) {
-                if (!c->dJobCost) {
-                    HIPCK(c, hipMalloc((void**)&c->dJobCost, job_cost_bytes(c)));
-                    HIPCK(c, hipHostMalloc((void**)&c->hJobCost, job_cost_bytes(c), hipHostMallocDefault));
-                    HIPCK(c, hipEventCreateWithFlags(&c->jobCostCopied, hipEventDisableTiming));
-                } else HIPCK(c, hipStreamWaitEvent(st, c->jobCostCopied, 0));      // behind an earlier measurement that a camera change abandoned
-                HIPCK(c, hipMemsetAsync(c->dJobCost, 0, job_cost_bytes(c), st));
-            }
-        }
+        Launch L; L.st = st; L.ev = ev; L.slab = slab; L.sppFirst = spp_first + f0 * passes; L.nf = nf; L.passes = passes; L.windows = (nf + 63u) / 64u;
+        if ((r = tuner_prepare(c, L))) return r;                       // single-window launches: latency mode (block table, tile-cost measurement)
+        if ((r = planner_prepare(c, L))) return r;                     // jobs: tile-cost measurement, kernel choice, plan (block table + pool split) or plain launch
         HIPCK(c, hipEventRecord(ev.a, st));
-        // Which render kernel: the stream pool executes a third fewer instructions per sample, but its wavefronts own 128 streams for 64 lanes, so the most
-        // expensive tiles take about twice as long per wavefront; a launch that is not many times larger than the machine (4 096 - 5 120 wavefronts in
-        // flight) ends on those and is faster with one stream per lane.  Measured cross-over (tools/crossover.py, bench.py --steps): bunny 1280x720 at 17 - 20
-        // windows (20 windows: 81.0 ms pool, 87.6 ms tiles), TLAS scene at ~28, watch-tower 1920x1080 at 7 — 56 000 ... 100 000 (tile, window) pairs; the
-        // threshold sits at the low end of that range.
-        // With the tile costs known (most expensive first + split, see split_point) the pool is never slower than one stream per lane from ~12 windows of 720p on
-        // (tools/split_probe.py: bunny 14 windows 57.8 against 59.6 ms, two-level scene 16 windows 79 against 94 ms, watch-tower 1080p 7 windows 155.6 against 161.1 ms).
-        const uint64_t minWaves = c->poolMinWaves != 65000u ? c->poolMinWaves : (c->jobCostValid ? 43000u : 65000u);
-        const bool pool = c->usePool && c->hScene.ref16ok && (uint64_t)c->tileCount * ((nf + 63u) / 64u) >= minWaves && (c->poolMinWaves == 0 || nf > 64u);
-        hipError_t le;
-        if (hook("CRT_DEBUG_FAIL_LAUNCH")) le = hipErrorInvalidConfiguration;       // tests: the runtime refuses the launch
-        else {
-            const uint32_t windows = (nf + 63u) / 64u;
-            uint32_t head = 0, jobBlocks = 0;
-            if (nf > 64u && c->jobCostValid) { if ((r = install_job_plan(c, windows, nf, pool))) return r; head = c->jobHead; jobBlocks = c->jobBlocks; }
-            if (jobBlocks) HIPCK(c, hipStreamWaitEvent(st, c->jobDescReady, 0));
-            le = hipSuccess;
-            unsigned long long* jobClk = nullptr;
-            if (wantJobCost) {                                                 // what adopt_job_costs needs to know about the measuring launch
-                jobClk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->dJobCost) + job_cost_clk_offset(c));
-                c->recPool = pool; c->recWindows = windows;
-                c->recWaves = pool ? c->tileCount * ((nf + crt_pool_streams(nf) - 1u) / crt_pool_streams(nf)) : c->tileCount * windows;
-                c->recResident = pool ? 4096u : 5120u;                            // 4 / 5 wavefronts per SIMD (render_pool_kernel / render_tiles_kernel)
-            }
-            // a second kernel of the same launch on another stream: released by the launch's start event, joined before its end event
-            auto join = [&](hipStream_t other) -> hipError_t {
-                if (other == st) return hipSuccess;
-                hipError_t e = hipSuccess;
-                if (c->splitEvents.size() < 32) { hipEvent_t ne; e = hipEventCreateWithFlags(&ne, hipEventDisableTiming); if (e == hipSuccess) c->splitEvents.push_back(ne); }
-                if (e == hipSuccess) { hipEvent_t je = c->splitEvents[c->splitSeq++ % c->splitEvents.size()]; e = hipEventRecord(je, other); if (e == hipSuccess) e = hipStreamWaitEvent(st, je, 0); }
-                return e;
-            };
-            // a block table = [wide blocks: render_tiles_kernel on this launch's stream][blocks of <= 8 lanes: render_narrow_kernel on the next stream, submitted first —
-            // they are the most expensive tiles' and the launch ends on them]
-            auto launch_table = [&](const uint32_t* desc, uint32_t nAll, uint32_t nWide, uint32_t* cost) -> hipError_t {
-                hipError_t e = hipSuccess;
-                hipStream_t sn = st;
-                if (nAll > nWide) {
-                    if (!c->narrowStream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); e = hipStreamCreateWithPriority(&c->narrowStream, hipStreamNonBlocking, hi); if (e != hipSuccess) return e; }
-                    sn = c->narrowStream;
-                    e = hipStreamWaitEvent(sn, ev.a, 0);
-                    if (e == hipSuccess) e = crt_launch_render_narrow(&c->hScene, slab, c->dCounters, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                                                      spp_first + f0 * passes, nf, passes, c->ldsBytes, desc + nWide, nAll - nWide, cost, sn);
-                }
-                if (e == hipSuccess && nWide)
-                    e = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                          spp_first + f0 * passes, nf, passes, c->ldsBytes, 0, desc, nWide, cost, 0u, nullptr, st);
-                if (e == hipSuccess) e = join(sn);                                 // (after both are submitted: the two kernels run side by side)
-                return e;
-            };
-            if (pool) {
-                void* scratch = (char*)slab + (size_t)windows * sample_bytes_per_window(c, passes);
-                hipStream_t st2 = st;
-                if (jobBlocks) {
-                    // the expensive tiles first, through the block table, on this launch's stream; the pool for the rest on the next stream, released by the same start event
-                    le = launch_table(c->dJobDesc, jobBlocks, c->jobBlocksWide, nullptr);
-                    st2 = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
-                    if (le == hipSuccess && st2 != st) le = hipStreamWaitEvent(st2, ev.a, 0);
-                }
-                if (le == hipSuccess)
-                    le = crt_launch_render_pool(&c->hScene, slab, scratch, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                                spp_first + f0 * passes, nf, passes, c->cfg.collectStats, jobBlocks ? head : 0u, wantJobCost ? c->dJobCost : nullptr, jobClk, st2);
-                if (jobBlocks && le == hipSuccess) le = join(st2);
-            } else if (jobBlocks) {
-                le = launch_table(c->dJobDesc, jobBlocks, c->jobBlocksWide, nullptr);
-            } else if (blockDesc && nBlocks) {
-                le = launch_table(blockDesc, nBlocks, c->nBlocksWide, wantCost ? c->dTileCost : nullptr);
-            } else {
-                le = crt_launch_render(&c->hScene, slab, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
-                                       spp_first + f0 * passes, nf, passes, c->ldsBytes, c->cfg.collectStats, nullptr, 0u,
-                                       wantCost ? c->dTileCost : (wantJobCost ? c->dJobCost : nullptr), 0u, jobClk, st);
-            }
-            if (jobBlocks && le == hipSuccess) c->splitLaunches++;
-        }
+        const bool pool = L.pool, wantCost = L.wantCost, wantJobCost = L.wantJobCost;
+        const hipError_t le = hook("CRT_DEBUG_FAIL_LAUNCH") ? hipErrorInvalidConfiguration /* tests: the runtime refuses the launch */ : launch_render_kernels(c, L);
         if (le != hipSuccess) {
             // a launch that failed has rendered nothing: its timing pair goes back (pairGuard), the accumulator and the region bookkeeping stay untouched —
             // the frames before it are in, this one and the rest are not — and the error is reported

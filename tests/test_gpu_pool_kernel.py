@@ -124,6 +124,7 @@ def test_split_jobs_match_the_oracle(crt, orc, monkeypatch, xml, kind, W, H, fra
     """Jobs after the first one know what every tile costs: they dispatch the tiles most expensive first and render the most expensive ones with a concurrent
     render_tiles_kernel launch driven by a block table (abi.cpp plan_job).  Same pixels, same counters, whatever the split."""
     monkeypatch.setenv("CRT_RENDER_KERNEL", "tiles" if force == "tiles" else "pool_always")
+    monkeypatch.setenv("CRT_PLAN_NO_TRIAL", "1")                             # (every later job planned; the planned-against-plain trial has its own test below)
     if force == "tiles": monkeypatch.setenv("CRT_SPLIT_FORCE", "7")          # a job below the pool's size: everything through the table, 7 tiles with narrow wavefronts
     elif force is not None: monkeypatch.setenv("CRT_SPLIT_FORCE", force)     # (None: whatever the planner decides for this small image)
     o, _ = orc.load_scene(scene_path(xml), kind, ASSETS)
@@ -138,3 +139,21 @@ def test_split_jobs_match_the_oracle(crt, orc, monkeypatch, xml, kind, W, H, fra
         assert ctx.counters()["rays"] == o.counters()["rays"]
         splits.append(ctx.timing()["split_launches"])
     assert splits[0] == 0 and (force is None or splits[-1] == 1), splits          # the first job measures, later ones split
+
+
+def test_planned_jobs_are_checked_against_the_plain_launch(crt, orc, monkeypatch):
+    """the plan is a model, so a repeating job shape is tried both ways — planned, then plain — and the faster launch is kept (abi.cpp
+    planner_prepare).  Whatever the sequence decides, every launch renders the oracle's pixels; launch 2 is the planned one, launch 3 the plain one."""
+    monkeypatch.setenv("CRT_RENDER_KERNEL", "pool_always"); monkeypatch.setenv("CRT_SPLIT_FORCE", "5")
+    W, H, frames = 96, 64, 200
+    o, _ = orc.load_scene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    o.renderer_init(W, H); o.render(frames, 4)
+    want = o.accumulator()
+    hs = crt.HostScene(scene_path("bunny_scene.xml"), 0, ASSETS)
+    ctx = crt.Context(W, H); hs.upload(ctx)
+    splits = []
+    for i in range(6):
+        ctx.clear(); ctx.render(1, frames, 1); ctx.sync()
+        assert np.array_equal(ctx.accumulator(), want), i
+        splits.append(ctx.timing()["split_launches"])
+    assert splits[:3] == [0, 1, 0] and splits[3] == splits[4] == splits[5], splits      # measure, planned, plain, then the winner for good
