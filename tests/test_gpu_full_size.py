@@ -205,3 +205,20 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and "sample" in cb
     assert d["value"] > cb["value"]        # (a 320x192 job is latency-bound on the GPU; the ratio that matters is the full-size bench line's)
+
+
+def test_bench_starts_its_own_ranks_for_gpus_2():
+    """`bench.py --gpus 2` without an external launcher spawns its two ranks itself (torch.distributed.run on 127.0.0.1) before touching the GPU; both
+    ranks share the box's one GPU here and talk gloo (CRT_BENCH_BACKEND), rank 0 prints the one line: tile ownership, ONE collective, rccl_ranks = 2"""
+    import json, os, subprocess, sys
+    from conftest import REPO
+    env = dict(os.environ, CRT_BENCH_BACKEND="gloo", CRT_BENCH_CPU_BUDGET_S="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "320", "--height", "192", "--no-single-render"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rccl_ranks"] == 2 and d["config"]["collective"] in ("reduce", "all_reduce")
+    assert "dealt round-robin over 2 ranks" in d["config"]["workload"] and d["value"] > 0 and "cpu_baseline" not in d
