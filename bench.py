@@ -245,7 +245,7 @@ def main():
     # latency of ONE step on its own (submit, wait), next to the job throughput: the literal "one WxH / SPP-spp render"
     lat = []
     if not args.no_single_render:
-        for i in range(16):                         # (the back end tunes its latency mode over the first 10 single-window launches: tile costs -> block tables, confirms and keeps the fastest)
+        for i in range(16):                         # (the back end tunes its latency mode over the first 7 single-window launches: probe -> solved block tables, confirms and keeps the fastest)
             ctx.clear(); ctx.sync()
             t1 = time.perf_counter()
             ctx.render(1, SPP, 1)
@@ -324,8 +324,8 @@ def main():
                    "collective": None if dist is None else collective["used"], "rccl_ranks": None if dist is None else dist.get_world_size(), "backend": None if dist is None else dist.get_backend(),
                    "rays_per_step_rank0": round(counts["rays"]), "rays_per_primary": round(counts["rays"] / max(counts["primary"], 1), 4),
                    "triangles": scene.triangle_count(), "parallelism": "tile-wave x%d" % world},
-        "single_render": None if not single_ms else {"ms": round(single_ms, 3), "mrays_s": round(counts["rays"] / single_ms / 1e3, 1), "first_ms": round(lat[0], 3), "untuned_ms": round(lat[1], 3),
-                                                     "what": "ONE %dx%d / %d-spp render on an idle GPU: clear, crt_render(1, %d, 1), sync (16 renders; the first 11 let the back end's latency mode measure the tiles and settle, `ms` = median of the last 5, `first_ms` / `untuned_ms` = renders 1 and 2: a block table built from the 0.4-ms cost probe that precedes the first render after a camera / scene change, while the tile costs are measured)" % (W, H, SPP, SPP)},
+        "single_render": None if not single_ms else {"ms": round(single_ms, 3), "mrays_s": round(counts["rays"] / single_ms / 1e3, 1), "first_ms": round(lat[0], 3), "second_ms": round(lat[1], 3),
+                                                     "what": "ONE %dx%d / %d-spp render on an idle GPU: clear, crt_render(1, %d, 1), sync (16 renders; `first_ms` = the first render after a camera / scene change, cost probe included: its block table is solved from the probe's 512 paths per tile; `second_ms` = the table solved from the tile costs the first render measured; renders 2-7 are the latency mode's stages and confirmations, `ms` = median of the last 5)" % (W, H, SPP, SPP)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "hbm_actual_frac": None if not traffic or job_launch_ms <= 0 else round(traffic / (job_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

@@ -16,7 +16,10 @@
 #include <string>
 #include <algorithm>
 #include <vector>
+#include <chrono>
 
+extern "C" uint32_t crt_render_resident_waves(int, int, uint32_t);
+extern "C" uint32_t crt_probe_paths();
 extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, const uint32_t*, uint32_t, uint32_t*, uint32_t, unsigned long long*, hipStream_t);
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
 extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t*, unsigned long long*, hipStream_t);
@@ -111,7 +114,7 @@ struct crt_ctx {
     // Latency mode of single-window launches (render_tiles_kernel's block table), driven by measurement — see next_block_table.  Stage 0 = one wavefront per tile;
     // stages 1 .. kLatStages = block tables, each built from the tile costs measured under the best stage so far; afterwards the fastest stage is used
     // (HIP event durations of the launches themselves; identical pixels whatever the table).
-    static constexpr int kLatStages = 6;       // (the bunny settles by stage 3, the two-level scene still gains at 5; bolder aims do not get lower: DESIGN.md §5)
+    static constexpr int kLatStages = 4;       // (round 3: the stages are solved, not stepped, and agree within launch-to-launch scatter from stage 1 on; round 2's stepping tuner needed 6)
     double tuneMs[kLatStages + 1] = {}; int tuneCount[kLatStages + 1] = {};
     hipEvent_t lastRenderEnd = nullptr;   // end event of the most recent render launch (owned by the timing lists)
     int latStage = 0;              // stage of the table on the device (0: none yet)
@@ -119,6 +122,7 @@ struct crt_ctx {
     bool latDone = false;          // all stages measured, the fastest one's table is (being) installed
     bool latConfirming = false; std::vector<int> latQueue;      // after the last stage: the two fastest stages are timed once more
     bool latWarm = false;          // stage 0 has been measured once already (the first launch after an upload runs cold: it is measured twice)
+    uint32_t latSlots = 0;         // wavefronts of render_tiles_kernel the device holds at once (0: not asked yet)
     bool latProbed = false;        // the cost probe has run for this camera / scene: stage 0 is a block table built from its estimates (latL[0]), not one wavefront per tile
     std::vector<uint8_t> latL[kLatStages + 1];          // lanes per wavefront of every tile, per stage ([0]: all 64)
     std::vector<uint32_t> latCost[kLatStages + 1];      // measured tile costs, per stage
@@ -608,7 +612,7 @@ int crt_upload_scene(crt_ctx* c, const crt_scene_desc* sd)
     }
     if (hook("CRT_DEBUG_NO_ROOTPAIR")) s.rootIsPair = 0;                            // tests: every ray starts at the root reference instead
     s.stackDepth = s.bvhStack + ((sd->kind == CRT_SCENE_TLAS) ? tlasHeight + 1 : 0);   // + TLAS pushes + the return marker
-    c->ldsBytes = s.stackDepth * 64u * 4u;
+    c->ldsBytes = s.stackDepth * 64u * 4u; c->latSlots = 0;
     if (const char* e = hook("CRT_DEBUG_EXTRA_LDS")) c->ldsBytes += (uint32_t)atoi(e);   // occupancy experiments only
     if (c->ldsBytes + 15u * 256u > 64u * 1024u) return c->fail(CRT_ERR_UNSUPPORTED, "tree height %u (+TLAS %u) needs %u bytes of LDS traversal stack per wave (> 64 KiB)", maxHeight, tlasHeight, c->ldsBytes);
     // world-space bounds of all meshes (FileScene: root box of the BVH; TLAS: root box of the TLAS) for the dispatch-order heuristic
@@ -751,7 +755,7 @@ int crt_update_scene(crt_ctx* c, const crt_scene_desc* sd, uint32_t what)
         touch((size_t)f.tlasOff, (size_t)f.shadeOff);
         crt::Scene& s = c->hScene;
         s.stackDepth = s.bvhStack + tlasHeight + 1;
-        c->ldsBytes = s.stackDepth * 64u * 4u;
+        c->ldsBytes = s.stackDepth * 64u * 4u; c->latSlots = 0;
     }
     if (lo >= hi) return CRT_OK;
     // In-place rewrite, no allocation of device memory and no host wait for the GPU: the copy runs on the main stream, which is ordered behind every
@@ -911,6 +915,40 @@ extern "C" int crt_debug_next_lanes(const uint8_t* lanes, const uint32_t* cost, 
     return CRT_OK;
 }
 
+// The table of a stage, solved instead of stepped (round 3): every tile ran `lanes[i]`-wide wavefronts and its slowest took `cost[i]` (or: lanes 64 and the probe's estimate).
+// A narrower table is a faster launch as long as the device holds ALL its wavefronts at once — a wavefront that has to wait for a slot starts its chain late — so the aim
+// T is the LOWEST one whose table fits `budget` wavefronts (bisection; waves(T) falls as T rises), but not below what the most expensive tile takes as one-lane wavefronts,
+// which bounds the launch anyway: cheaper tiles are not split to beat a time nothing can reach.  Returns T.
+static double solve_block_table(const std::vector<uint8_t>& lanes, const std::vector<uint32_t>& cost, double budget, std::vector<uint8_t>& out)
+{
+    const size_t n = cost.size();
+    double topUnit = 0; for (size_t i = 0; i < n; i++) topUnit = std::max(topUnit, (double)cost[i] / kLatG[lat_index(lanes[i])]);
+    out.assign(n, 64);
+    if (topUnit <= 0) return 0;
+    auto waves = [&](double T) { double w = 0; for (size_t i = 0; i < n; i++) w += 64.0 / next_lanes(lanes[i], cost[i], T); return w; };
+    double lo = kLatG[6] * topUnit, hi = topUnit;
+    if (waves(lo) > budget) { for (int it = 0; it < 14; it++) { const double mid = 0.5 * (lo + hi); if (waves(mid) <= budget) hi = mid; else lo = mid; } lo = hi; }
+    for (size_t i = 0; i < n; i++) out[i] = next_lanes(lanes[i], cost[i], lo);
+    return lo;
+}
+// tests (no GPU needed): the solved table for n tiles and a wavefront budget; returns the aim through *T
+extern "C" int crt_debug_solve_block_table(const uint8_t* lanes, const uint32_t* cost, uint32_t n, double budget, uint8_t* out, double* T)
+{
+    if (!lanes || !cost || !out) return CRT_ERR_INVALID;
+    for (uint32_t i = 0; i < n; i++) if (lanes[i] == 0 || lanes[i] > 64 || (64 % lanes[i]) != 0) return CRT_ERR_INVALID;
+    std::vector<uint8_t> L; const double t = solve_block_table(std::vector<uint8_t>(lanes, lanes + n), std::vector<uint32_t>(cost, cost + n), budget, L);
+    if (n) memcpy(out, L.data(), n);
+    if (T) *T = t;
+    return CRT_OK;
+}
+static double lat_budget(crt_ctx* c)
+{
+    if (!c->latSlots) c->latSlots = crt_render_resident_waves(c->cfg.device, c->hScene.kind, c->ldsBytes);
+    double share = 0.98;
+    if (const char* e = hook("CRT_LAT_BUDGET")) { const double v = atof(e); if (v > 0) share = v; }
+    return share * (double)c->latSlots;
+}
+
 static int upload_block_table(crt_ctx* c, const std::vector<uint8_t>& lanes, const std::vector<uint32_t>& cost)
 {
     const uint32_t n = c->tileCount;
@@ -948,7 +986,7 @@ static int next_block_table(crt_ctx* c)
 {
     const uint32_t n = c->tileCount; const int K = crt_ctx::kLatStages;
     const int s = c->costStage;
-    if (s == 0 && !c->latWarm) { c->latWarm = true; return 0; }          // measure the one-wave launch once more, warm
+    if (s == 0 && !c->latWarm && !c->latProbed) { c->latWarm = true; return 0; }          // measure the one-wave launch once more, warm (a probed stage 0 is not the base of anything: every stage is solved from the one before it)
     c->latCost[s].assign(c->hTileCost, c->hTileCost + n);
     if (s == 0 && !c->latProbed) c->latL[0].assign(n, 64);
     if (c->tuneCount[s] && (c->latBest == s || !c->tuneCount[c->latBest] || c->tuneMs[s] < c->tuneMs[c->latBest])) c->latBest = s;
@@ -995,11 +1033,17 @@ static int next_block_table(crt_ctx* c)
         for (uint32_t i = 0; i < n; i++)
             for (const auto& st : steps) if (top > 0 && (double)baseC[i] >= st.first * (double)top) { L[i] = (uint8_t)st.second; break; }
     } else {
-        double aim = (s == 0 && !c->latProbed) ? 0.64 : 0.92;               // (a probed stage 0 is a narrowed table already: refine, do not halve again)
-        if (const char* e = hook("CRT_LAT_AIM")) { const double v = atof(e); if (s > 0 && v > 0) aim = v; }
-        for (uint32_t i = 0; i < n; i++) L[i] = next_lanes(baseL[i], baseC[i], aim * (double)top);
+        if (const char* e = hook("CRT_LAT_AIM")) {                          // diagnostics: the stepping tuner of round 2 (aim = a fraction of the base stage's slowest tile)
+            double aim = atof(e); if (!(aim > 0)) aim = (s == 0 && !c->latProbed) ? 0.64 : 0.92;
+            for (uint32_t i = 0; i < n; i++) L[i] = next_lanes(baseL[i], baseC[i], aim * (double)top);
+        } else {
+            // solved from the LATEST stage's measurement (each tile's cost at the width it just ran is the best estimate of its one-wave cost there is, whether or not
+            // that stage was the fastest); keeping the fastest stage guards the choice
+            const double T = solve_block_table(c->latL[s], c->latCost[s], lat_budget(c), L);
+            if (hook("CRT_LAT_VERBOSE")) fprintf(stderr, "[crt] stage %d: aim %.2f ms\n", s + 1, T * 1e-5);
+        }
     }
-    const int r = upload_block_table(c, L, baseC);
+    const int r = upload_block_table(c, L, (steps.empty() && !hook("CRT_LAT_AIM")) ? c->latCost[s] : baseC);
     if (r) return r;
     c->latStage = s + 1;
     return 0;
@@ -1386,8 +1430,8 @@ static hipError_t launch_render_kernels(crt_ctx* c, const Launch& L)
 }
 
 // The first single-window launch after a camera / scene change used to run one wavefront per tile (34 ms for the 720p bunny) because nothing was known about the
-// tiles.  Now a probe launch (render_narrow_kernel<.., true>: 64 paths per tile, ~0.3 ms) counts the steps those paths take and stage 0 of the latency mode is a
-// block table built from that estimate.  The call waits for the probe (the only host wait of crt_render, once per camera / scene).
+// tiles.  Now a probe launch (render_narrow_kernel<.., 1>: 512 paths per tile, two through every pixel, one per lane) counts the steps those paths take and stage 0 of the latency mode is a
+// block table solved from that estimate (solve_block_table).  The call waits for the probe (the only host wait of crt_render, once per camera / scene).
 static int probe_tile_costs(crt_ctx* c, hipStream_t st)
 {
     const uint32_t n = c->tileCount;
@@ -1396,23 +1440,36 @@ static int probe_tile_costs(crt_ctx* c, hipStream_t st)
         HIPCK(c, hipHostMalloc((void**)&c->hTileCost, (size_t)n * 4, hipHostMallocDefault));
         HIPCK(c, hipEventCreateWithFlags(&c->costCopied, hipEventDisableTiming));
     } else HIPCK(c, hipEventSynchronize(c->costCopied));                   // an earlier measurement that a camera change abandoned
+    const auto tp0 = std::chrono::steady_clock::now();
     HIPCK(c, crt_launch_probe(&c->hScene, c->tileFirst, c->tileStride, n, (uint32_t)c->tilesX, c->dTileCost, st));
     HIPCK(c, hipMemcpyAsync(c->hTileCost, c->dTileCost, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCK(c, hipEventRecord(c->costCopied, st));
     HIPCK(c, hipStreamSynchronize(st));
-    // steps of 64 paths -> an estimate in the units the tuner's model uses: only ratios matter (aims are fractions of the most expensive tile)
+    // steps of the probe's paths -> an estimate in the units the tuner's model uses: only ratios matter (aims are fractions of the most expensive tile)
+    const auto tp1 = std::chrono::steady_clock::now();
     std::vector<uint32_t>& est = c->latCost[0]; est.assign(c->hTileCost, c->hTileCost + n);
-    // "the most expensive tile" of a 64-path estimate is an outlier of its noise: the aim refers to the 98th percentile instead
-    uint32_t top = 0;
-    { std::vector<uint32_t> sorted(est); const size_t k = (size_t)((double)n * 0.98); std::nth_element(sorted.begin(), sorted.begin() + std::min<size_t>(k, n - 1), sorted.end()); top = sorted[std::min<size_t>(k, n - 1)]; }
+    // measured (tools/probe_quality.py; bunny, watch-tower, two-level scene): a tile's one-wavefront duration is AFFINE in the probe's step count — 84 - 113 ticks per step
+    // plus 3.7 - 4.8 ms that every tile pays for its 16 384 paths whatever they hit (ray generation, the sky lookup, the sample store): 15 - 22 steps' worth per probed path.
+    // With the constant added the estimate ranks the expensive tiles to 6 - 9 % (without: 10 - 20 %, the cheap half of them overrated).
+    for (uint32_t i = 0; i < n; i++) est[i] += 18u * crt_probe_paths();
     std::vector<uint8_t>& L = c->latL[0]; L.assign(n, 64);
-    double aim = 0.90;
-    if (const char* e = hook("CRT_LAT_PROBE_AIM")) aim = atof(e);
-    if (top > 0) for (uint32_t i = 0; i < n; i++) L[i] = next_lanes(64, est[i], aim * (double)top);
+    if (const char* e = hook("CRT_LAT_PROBE_AIM")) {                       // diagnostics: a fixed fraction of the 98th percentile (the first form of the probed stage)
+        uint32_t top = 0;
+        { std::vector<uint32_t> sorted(est); const size_t k = (size_t)((double)n * 0.98); std::nth_element(sorted.begin(), sorted.begin() + std::min<size_t>(k, n - 1), sorted.end()); top = sorted[std::min<size_t>(k, n - 1)]; }
+        const double aim = atof(e);
+        if (top > 0) for (uint32_t i = 0; i < n; i++) L[i] = next_lanes(64, est[i], aim * (double)top);
+    } else {
+        const std::vector<uint8_t> wide(n, 64);
+        solve_block_table(wide, est, lat_budget(c), L);
+    }
     c->latProbed = true;
     bool any = false; for (uint32_t i = 0; i < n; i++) any = any || L[i] != 64;
     if (!any) { c->latProbed = false; return 0; }                           // nothing to narrow: stage 0 stays one wavefront per tile
-    return upload_block_table(c, L, est);
+    const auto tp2 = std::chrono::steady_clock::now();
+    const int r = upload_block_table(c, L, est);
+    if (hook("CRT_LAT_VERBOSE")) { const auto tp3 = std::chrono::steady_clock::now(); auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[crt] cost probe: launch + wait %.3f ms, table solved in %.3f ms, uploaded in %.3f ms\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3)); }
+    return r;
 }
 
 int crt_render(crt_ctx* c, uint32_t spp_first, uint32_t frames, uint32_t passes)
@@ -1816,6 +1873,16 @@ extern "C" int crt_debug_tile_costs(crt_ctx* c, uint32_t* out)
     HIPCK(c, hipDeviceSynchronize());
     HIPCK(c, hipMemcpy(out, c->dTileCost, (size_t)c->tileCount * 4, hipMemcpyDeviceToHost));
     return CRT_OK;
+}
+
+// diagnostics (tools/probe_quality.py): lanes per wavefront and tile costs of one stage of the latency tuner ([0]: the probe's estimates when latProbed); returns the installed stage
+extern "C" int crt_debug_lat_stage(crt_ctx* c, int stage, uint8_t* lanes, uint32_t* cost)
+{
+    if (!c || stage < 0 || stage > crt_ctx::kLatStages) return CRT_ERR_INVALID;
+    if (c->latL[stage].size() != c->tileCount || c->latCost[stage].size() != c->tileCount) return CRT_ERR_STATE;
+    if (lanes) memcpy(lanes, c->latL[stage].data(), c->tileCount);
+    if (cost) memcpy(cost, c->latCost[stage].data(), (size_t)c->tileCount * 4);
+    return c->latStage;
 }
 
 extern "C" int crt_debug_tile_stamps(crt_ctx* c, uint64_t* out)

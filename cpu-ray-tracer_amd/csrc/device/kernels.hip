@@ -852,6 +852,17 @@ extern "C" hipError_t crt_launch_render(const crt::Scene* sc, void* slab, crt::C
     return hipGetLastError();
 }
 
+// how many wavefronts of render_tiles_kernel the device holds at once (registers: 5 per SIMD; LDS: the stack columns) — the size the latency tuner fits its block tables to
+extern "C" uint32_t crt_render_resident_waves(int device, int kind, uint32_t ldsBytes)
+{
+    int perCu = 0, cus = 0;
+    const size_t lds = (size_t)ldsBytes + 15u * 64u * 4u;
+    hipError_t e = kind == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, crt::render_tiles_kernel<0, false>, 64, lds)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, crt::render_tiles_kernel<1, false>, 64, lds);
+    if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || perCu <= 0 || cus <= 0) { (void)hipGetLastError(); return 5120u; }
+    return (uint32_t)perCu * (uint32_t)cus;
+}
+
 extern "C" hipError_t crt_launch_accumulate(const void* slab, void* acc, uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount,
                                             uint32_t tilesX, uint32_t W, uint32_t frames, uint32_t passes, hipStream_t stream)
 {

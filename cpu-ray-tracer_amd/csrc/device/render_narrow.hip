@@ -31,11 +31,12 @@ struct Rec { rec4 a, b, c, d; };                           // a fetched 64-byte 
 // per-lane LDS of a FileScene wavefront: [stackDepth references][stackDepth records of 16 dwords][15 throughput factors], dwords
 __device__ __host__ __forceinline__ uint32_t narrow_lane_dwords(uint32_t stackDepth) { return (stackDepth * 17u + 15u + 3u) & ~3u; }   // (a multiple of 4: the records are 16-byte accesses)
 
+constexpr uint32_t kProbeWaves = 8u;                       // cost probe: wavefronts (of 64 one-path lanes) per tile
 constexpr uint32_t kNarrowWaves = 4u;                      // wavefronts per workgroup: they share the treetop in LDS, each renders one block of the table
 
-// PROBE = true is the cost probe of the latency mode (abi.cpp probe_tile_costs): one wavefront per tile, lane l traces ONE path through pixel (2 (l % 8), 2 (l / 8)) of the
-// tile with a seed of its own, nothing is stored, and the wavefront leaves the number of traversal / shading steps its 64 paths took in tileCost[tile] — an estimate of
-// what the tile's streams will cost (a stream = 256 such paths), available ~0.3 ms after a camera or scene change instead of after a first full render.
+// PROBE = true is the cost probe of the latency mode (abi.cpp probe_tile_costs): kProbeWaves wavefronts per tile, lane l of wavefront q traces ONE path through pixel (4 l + q) % 256 of the
+// tile with a seed of its own (256 paths per tile per four wavefronts), nothing is stored, and every wavefront adds the number of traversal / shading steps its 64 paths took to tileCost[tile] (zeroed by the host) — an estimate of
+// what the tile's streams will cost (a stream = 256 such paths), available well under a millisecond after a camera or scene change instead of after a first full render.
 // MODE 0 = block-table wavefronts of <= kNarrowMaxLanes lanes (above), MODE 1 = the cost probe (PROBE),
 // MODE 2 / 3 = whole (tile, window) wavefronts, lane = frame, that trace Renderer::Sample through FileScene's KD-tree / uniform grid instead of the BVH
 // (crt_set_render_accel: the reference's shipped FileScene traces through the KD-tree, file_scene.h:10-12, file_scene.cpp:170-175) — the sequential form:
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, c
     const uint32_t entry = blockIdx.x * kNarrowWaves + wave;
     if (entry >= nBlocks) return;
     const uint32_t windowsAll = (frames + 63u) / 64u;
-    const uint32_t d = PROBE ? (entry | (6u << 22)) : ALT ? ((entry / windowsAll) | (6u << 22) | ((entry % windowsAll) << 25)) : blockDesc[entry];   // (probe / accelerator modes: all 64 lanes)
+    const uint32_t d = PROBE ? ((entry / kProbeWaves) | (6u << 22)) : ALT ? ((entry / windowsAll) | (6u << 22) | ((entry % windowsAll) << 25)) : blockDesc[entry];   // (probe / accelerator modes: all 64 lanes)
     const uint32_t tl = d & 0xffffu, laneBase = (d >> 16) & 63u, myLanes = 1u << ((d >> 22) & 7u), win = d >> 25;
     if (tl >= tileCount || (MODE == 0 && myLanes > kNarrowMaxLanes)) return;
     sppFirst += win * 64u * passes;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, c
     uint32_t nRays = 0, nPrimary = 0, nMesh = 0;
     const uint32_t items = PROBE ? 1u : 256u * passes;                            // (pixel, pass) pairs in stream order
     uint32_t seed = init_seed(tx + ty * (uint32_t)sc.W + (sppFirst + (laneBase + lane) * passes) * 1799u);   // renderer.cpp:120
-    if (PROBE) seed = init_seed(0x9e3779b9u ^ (tile * 64u + lane));
+    if (PROBE) seed = init_seed(0x9e3779b9u ^ ((tile * kProbeWaves + entry % kProbeWaves) * 64u + lane));
     uint32_t steps = 0;                                                           // probe: traversal + weighted shading steps of this lane's path
 
     // LDS of this lane
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, c
 
     for (uint32_t item = 0; item < items; item++) {
         // ---------------- ProcessTile + Camera::GetPrimaryRay (renderer.cpp:125-126, camera.h:23-30) ----------------
-        const uint32_t pix = PROBE ? ((lane & 7u) * 2u + (lane >> 3) * 32u) : ((passes == 1u) ? item : item / passes);
+        const uint32_t pix = PROBE ? ((lane * 4u + entry % kProbeWaves) & 255u) : ((passes == 1u) ? item : item / passes);
         const int x = (int)(tx * 16u + (pix & 15u)), y = (int)(ty * 16u + (pix >> 4));
         const float jy = rnd(seed);                                               // pinned: first draw is the y jitter
         const float jx = rnd(seed);
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, 4) void render_narrow_kernel(const Scene sc, c
             slab[((size_t)tl * 256u + pix) * (64u * passes) + ((laneBase + lane) * passes + pass)] = make_float4(L.x, L.y, L.z, 0.0f);
         } else if (L.x != L.x) steps++;                                            // (keeps the probe's shading arithmetic alive)
     }
-    if (PROBE) { const uint32_t sum = wave_sum(steps); if (lane == 0) tileCost[tl] = sum; return; }
+    if (PROBE) { const uint32_t sum = wave_sum(steps); if (lane == 0) atomicAdd(&tileCost[tl], sum); return; }
     // what this tile cost (100 MHz wall clock ticks; the longest of its wavefronts): the host's latency mode sizes the next launch's wavefronts with it
     if (tileCost && lane == 0) atomicMax(&tileCost[tl], (uint32_t)(wall_clock64() - clk0));
     atomicAdd(&counters->v[0], (unsigned long long)nRays);
@@ -307,15 +308,18 @@ extern "C" hipError_t crt_launch_render_narrow(const crt::Scene* sc, void* slab,
     return hipGetLastError();
 }
 
-// the latency mode's cost probe: one wavefront per owned tile, 64 paths each, step counts into tileCost[tile] (overwritten)
+// the latency mode's cost probe: kProbeWaves wavefronts per owned tile, 64 paths each, step counts summed into tileCost[tile]
+extern "C" uint32_t crt_probe_paths() { return 64u * crt::kProbeWaves; }
 extern "C" hipError_t crt_launch_probe(const crt::Scene* sc, uint32_t tileFirst, uint32_t tileStride, uint32_t tileCount, uint32_t tilesX, uint32_t* tileCost, hipStream_t stream)
 {
     if (tileCount == 0 || !tileCost || tileCount > 0x10000u) return hipSuccess;
     const crt::AltAccelDev none{};
-    dim3 grid((tileCount + crt::kNarrowWaves - 1u) / crt::kNarrowWaves), block(64u * crt::kNarrowWaves);
+    const uint32_t nProbe = tileCount * crt::kProbeWaves;
+    dim3 grid((nProbe + crt::kNarrowWaves - 1u) / crt::kNarrowWaves), block(64u * crt::kNarrowWaves);
     const uint32_t ldsBytes = crt::kNarrowWaves * (sc->stackDepth + 15u) * 64u * 4u;
-    if (sc->kind == 0) hipLaunchKernelGGL((crt::render_narrow_kernel<0, 1>), grid, block, ldsBytes, stream, *sc, none, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, tileCount, tileCost);
-    else hipLaunchKernelGGL((crt::render_narrow_kernel<1, 1>), grid, block, ldsBytes, stream, *sc, none, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, tileCount, tileCost);
+    if (hipMemsetAsync(tileCost, 0, (size_t)tileCount * 4, stream) != hipSuccess) return hipGetLastError();
+    if (sc->kind == 0) hipLaunchKernelGGL((crt::render_narrow_kernel<0, 1>), grid, block, ldsBytes, stream, *sc, none, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, nProbe, tileCost);
+    else hipLaunchKernelGGL((crt::render_narrow_kernel<1, 1>), grid, block, ldsBytes, stream, *sc, none, (float4*)nullptr, (crt::Counters*)nullptr, tileFirst, tileStride, tileCount, tilesX, 1u, 64u, 1u, (const uint32_t*)nullptr, nProbe, tileCost);
     return hipGetLastError();
 }
 

@@ -293,6 +293,36 @@ def test_latency_tuner_step_is_monotone_and_valid(crt):
     assert L.crt_debug_next_lanes(bad.ctypes.data, cost.ctypes.data, 1, 1.0, np.zeros(1, np.uint8).ctypes.data) != 0
 
 
+def test_latency_table_solve_fits_the_wavefront_budget(crt):
+    """abi.cpp solve_block_table (host logic, no GPU): the aim is the lowest one whose table fits the device's resident wavefronts, never below the most expensive tile's
+    one-lane time; a larger budget never gives a higher aim; cheap tiles are not split; with room for everything every expensive tile runs as narrow as the floor asks."""
+    L = crt.lib()
+    L.crt_debug_solve_block_table.restype = C.c_int
+    L.crt_debug_solve_block_table.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_void_p, C.POINTER(C.c_double)]
+    rng = np.random.default_rng(5)
+    n = 3600
+    cost = np.concatenate([rng.integers(50_000, 400_000, n - 300), rng.integers(800_000, 3_400_000, 300)]).astype(np.uint32)   # a sky / floor bulk and 300 tiles on the model
+    wide = np.full(n, 64, np.uint8)
+    prevT = None
+    for budget in (3600.0, 4000.0, 5017.0, 8000.0, 1e9):
+        out = np.zeros(n, np.uint8); T = C.c_double(0)
+        assert L.crt_debug_solve_block_table(wide.ctypes.data, cost.ctypes.data, n, budget, out.ctypes.data, C.byref(T)) == 0
+        waves = int((64 // out.astype(np.int64)).sum())
+        assert np.all(np.isin(out, [64, 32, 16, 8, 4, 2, 1]))
+        assert waves <= max(budget, n) * 1.001, (budget, waves)
+        assert T.value >= 0.48 * cost.max() * 0.999                        # the floor: the most expensive tile as one-lane wavefronts
+        assert np.all(out[cost < 0.4 * T.value] == 64)                      # cheap tiles stay one wavefront
+        if prevT is not None: assert T.value <= prevT * 1.0001
+        prevT = T.value
+    assert abs(prevT - 0.48 * cost.max()) <= 0.01 * cost.max()              # unlimited budget: the floor itself
+    # measured under a narrowed table: the cost at the width a tile ran is scaled back to its one-wavefront cost before the solve
+    lanes = rng.choice(np.array([64, 16, 2], np.uint8), n); out2 = np.zeros(n, np.uint8)
+    assert L.crt_debug_solve_block_table(lanes.ctypes.data, cost.ctypes.data, n, 5017.0, out2.ctypes.data, None) == 0
+    assert int((64 // out2.astype(np.int64)).sum()) <= 5017 * 1.001
+    bad = np.array([5], np.uint8)
+    assert L.crt_debug_solve_block_table(bad.ctypes.data, cost.ctypes.data, 1, 10.0, out.ctypes.data, None) != 0
+
+
 def test_primitive_scene_host_front_matches_the_oracle_and_det_trig_is_accurate(crt, orc):
     """PrimitiveScene's constructor + SetTime on the host front (csrc/host/primitive_scene.cpp) against the oracle's restatement (parity unpinned: both by this repo),
     and the deterministic double-precision acos / cos both the oracle and the HIP kernel use for the torus against libm (<= 1 ulp)."""

@@ -17,7 +17,9 @@ ctx = crt.Context(W, H); sc.upload(ctx); ctx.reserve(64, 1)
 # warm the process (code objects, slab pool) with another camera, then measure from a camera change on: first_ms = the first render after it
 ctx.set_camera_state((0.3, 0.2, -2.2), (0.0, 0.0, 1.0)); ctx.render(1, 64, 1); ctx.sync()
 ctx.set_camera_state((0.0, 0.0, -2.0), (0.0, 0.0, -1.0))
-ts = []
+ts = []; ks = []; subs = []
+k0 = ctx.timing()["render_kernel_ms"]
 for i in range(n):
-    ctx.clear(); ctx.sync(); t0 = time.perf_counter(); ctx.render(1, 64, 1); ctx.sync(); ts.append((time.perf_counter() - t0) * 1e3)
-print(json.dumps({"scene": xml, "size": [W, H], "renders_ms": [round(t, 2) for t in ts], "first_ms": round(ts[0], 2), "settled_ms": round(float(np.median(ts[-5:])), 2), "best_ms": round(min(ts), 2)}))
+    ctx.clear(); ctx.sync(); t0 = time.perf_counter(); ctx.render(1, 64, 1); t1 = time.perf_counter(); ctx.sync(); ts.append((time.perf_counter() - t0) * 1e3); subs.append((t1 - t0) * 1e3)
+    k1 = ctx.timing()["render_kernel_ms"]; ks.append(k1 - k0); k0 = k1
+print(json.dumps({"scene": xml, "size": [W, H], "renders_ms": [round(t, 2) for t in ts], "render_kernel_ms": [round(t, 2) for t in ks], "submit_ms": [round(t, 2) for t in subs], "first_ms": round(ts[0], 2), "settled_ms": round(float(np.median(ts[-5:])), 2), "best_ms": round(min(ts), 2)}))
