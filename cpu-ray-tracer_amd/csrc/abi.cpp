@@ -28,7 +28,7 @@ extern "C" uint32_t crt_narrow_max_lanes(void);
 extern "C" hipError_t crt_launch_probe(const crt::Scene*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, hipStream_t);
 extern "C" hipError_t crt_launch_render_narrow(const crt::Scene*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*, hipStream_t);
 extern "C" hipError_t crt_launch_accumulate(const void*, void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
-extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_find_nearest(const crt::Scene*, const void*, void*, uint32_t, crt::Counters*, uint32_t, uint32_t*, hipStream_t);
 namespace crt { struct AltAccelDev; }
 extern "C" hipError_t crt_launch_whitted(const crt::Scene*, int, const crt::AltAccelDev*, void*, uint32_t*, crt::Counters*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_render_alt(int, const crt::Scene*, const crt::AltAccelDev*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
@@ -57,7 +57,7 @@ struct PrimDev {                          // = device/render_prim.hip
 extern "C" hipError_t crt_launch_find_nearest_prim(const crt::PrimDev*, const void*, void*, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_render_prim(const crt::Scene*, const crt::PrimDev*, void*, crt::Counters*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t crt_launch_check_reciprocals(unsigned long long*, hipStream_t);
-extern "C" hipError_t crt_launch_find_nearest_alt(int, const crt::Scene*, const crt::AltAccelDev*, const void*, void*, uint32_t, hipStream_t);
+extern "C" hipError_t crt_launch_find_nearest_alt(int, const crt::Scene*, const crt::AltAccelDev*, const void*, void*, uint32_t, uint32_t*, hipStream_t);
 
 namespace {
 
@@ -94,6 +94,7 @@ struct crt_ctx {
     std::vector<hipEvent_t> doneEvents;
     crt::Scene hScene{};
     crt::Counters* dCounters = nullptr;
+    uint32_t* dQueryCursor = nullptr;      // the ray cursor of the persistent query kernels (zeroed by each launch)
     uint32_t* dPixels = nullptr; float* dTileSums = nullptr;
     unsigned long long* dTileClocks = nullptr;
     std::vector<void*> sceneAllocs;
@@ -305,6 +306,7 @@ int crt_create(crt_ctx** out, const crt_config* cfg)
     if ((e = hipMemsetAsync(c->dTileSums, 0, (size_t)tiles * 4, c->stream)) != hipSuccess) return bail(e, "hipMemset(tileSums)");
     if ((e = hipMalloc((void**)&c->dCounters, sizeof(crt::Counters))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemsetAsync(c->dCounters, 0, sizeof(crt::Counters), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
+    if ((e = hipMalloc((void**)&c->dQueryCursor, 64)) != hipSuccess) return bail(e, "hipMalloc(query cursor)");
     if (c->cfg.collectStats && count > 0) {
         if ((e = hipMalloc((void**)&c->dTileClocks, (size_t)count * 144)) != hipSuccess) return bail(e, "hipMalloc(tileClocks)");
         if ((e = hipMemsetAsync(c->dTileClocks, 0, (size_t)count * 144, c->stream)) != hipSuccess) return bail(e, "hipMemset(tileClocks)");
@@ -345,6 +347,7 @@ void crt_destroy(crt_ctx* c)
     if (c->dPixels) (void)hipFree(c->dPixels);
     if (c->dTileSums) (void)hipFree(c->dTileSums);
     if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->dQueryCursor) (void)hipFree(c->dQueryCursor);
     if (c->dTileClocks) (void)hipFree(c->dTileClocks);
     if (c->dTileOrder) (void)hipFree(c->dTileOrder);
     if (c->dTileCost) (void)hipFree(c->dTileCost);
@@ -1638,7 +1641,7 @@ int crt_find_nearest(crt_ctx* c, const crt_ray* rays, crt_hit* hits, size_t n)
     void *dR = c->dQueryRays, *dH = c->dQueryHits;
     HIPCK(c, hipMemcpyAsync(dR, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, c->stream));
     if (c->havePrim) HIPCK(c, crt_launch_find_nearest_prim(&c->prim, dR, dH, (uint32_t)n, c->stream));
-    else HIPCK(c, crt_launch_find_nearest(&c->hScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->stream));
+    else HIPCK(c, crt_launch_find_nearest(&c->hScene, dR, dH, (uint32_t)n, c->dCounters, c->ldsBytes, c->dQueryCursor, c->stream));
     HIPCK(c, hipMemcpyAsync(hits, dH, n * sizeof(crt_hit), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
@@ -1770,7 +1773,7 @@ int crt_find_nearest_alt(crt_ctx* c, int kind, const crt_ray* rays, crt_hit* hit
         c->queryCap = n;
     }
     HIPCK(c, hipMemcpyAsync(c->dQueryRays, rays, n * sizeof(crt_ray), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, crt_launch_find_nearest_alt(kind, &c->hScene, &c->alt, c->dQueryRays, c->dQueryHits, (uint32_t)n, c->stream));
+    HIPCK(c, crt_launch_find_nearest_alt(kind, &c->hScene, &c->alt, c->dQueryRays, c->dQueryHits, (uint32_t)n, c->dQueryCursor, c->stream));
     HIPCK(c, hipMemcpyAsync(hits, c->dQueryHits, n * sizeof(crt_hit), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;

@@ -528,29 +528,112 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const float4* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// find_nearest_kernel: one ray per lane, reference traversal order (reports Ray::traversed / tested)
+// find_nearest_kernel: scene.FindNearest for a buffer of rays in the reference's traversal order (reports Ray::traversed / tested as bvh.cpp:224-258 and
+// tlas_bvh.cpp:83-111 count their loop trips).  Persistent-wave form (round 3; before: one ray per lane for the whole launch, 19 % of the lanes busy): a wavefront
+// draws rays from a launch-wide cursor, a lane whose ray is finished takes the next one as soon as a quarter of the wavefront is idle, and a trip of the loop runs
+// each kind of step once for the lanes that are at it — TLAS node / leaf, BVH node, ONE triangle of a leaf — exactly the steps of find_nearest_seq (dev_common.h),
+// which the render kernels' sequential forms still call.
 // ------------------------------------------------------------------------------------------------------------
 struct RayIn { float O[3]; float D[3]; int32_t inside; };
 struct HitOut { float t, u, v; int32_t objIdx, triIdx, traversed, tested; };
+constexpr uint32_t kQueryRefill = 16u;                                   // idle lanes that trigger the next draw from the cursor
 
 __global__ __launch_bounds__(64) void find_nearest_kernel(const Scene sc, const RayIn* __restrict__ rays,
-                                                           HitOut* __restrict__ hits, uint32_t n, Counters* __restrict__ counters)
+                                                           HitOut* __restrict__ hits, uint32_t n, Counters* __restrict__ counters, uint32_t* __restrict__ cursor)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t i = blockIdx.x * 64u + lane;
+    const char* __restrict__ g = sc.geom;
+    uint32_t* stk = lds + lane;                                           // BVH entries of this lane's column: entry i at [i * 64]
+    uint32_t* tstk = stk + sc.bvhStack * 64;                              // TLAS entries above them
     Cnt cn; cn.rays = cn.primary = cn.interior = cn.leaf = cn.tri = cn.tlas = cn.visits = cn.meshhits = 0;
-    if (i < n) {
-        const RayIn r = rays[i];
-        f3 O = mk3(r.O[0], r.O[1], r.O[2]), D = mk3(r.D[0], r.D[1], r.D[2]);
-        f3 rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);                                       // Ray ctor, template/ray.h:15-24
-        Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
-        int traversed = 0, tested = 0;
-        find_nearest_seq(sc, O, D, rD, h, lds + lane, cn, traversed, tested);
-        int triIdx = h.triIdx;
-        if (sc.kind != 0 && h.objIdx >= 2) triIdx -= (int)asu(ldg(sc.geom, sc.instOff + (uint32_t)(h.objIdx - 2) * 128u + 48u).x);   // - Instance::shadeBase
-        HitOut o; o.t = h.t; o.u = h.u; o.v = h.v; o.objIdx = h.objIdx; o.triIdx = triIdx; o.traversed = traversed; o.tested = tested;
-        hits[i] = o;
+    // the ray in this lane
+    uint32_t mode = 0u;                                                   // 0 idle, 1 at a BVH reference (`cur`), 2 inside a leaf (`leafAt`), 3 at a TLAS reference (`tcur`), 4 finished
+    uint32_t idx = 0; f3 O = mk3(0, 0, 0), D = O, rD = O, Oo = O, Do = O, rDo = O;   // world-space ray; the ray the BVH is walked with (object space inside a BLAS)
+    Hit h; h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1;
+    int traversed = 0, tested = 0;
+    uint32_t cur = 0, sp = 0, tcur = 0, tsp = 0, leafAt = 0;
+    bool more = true;                                                     // wave-uniform: the cursor has rays left
+    for (;;) {
+        // ---------------- refill: idle lanes draw the next rays ----------------
+        const uint64_t mIdle = __builtin_amdgcn_ballot_w64(mode == 0u);
+        const uint32_t nIdle = (uint32_t)__popcll(mIdle);
+        if (more && nIdle >= kQueryRefill) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cursor, nIdle);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            more = base + nIdle < n;
+            const uint32_t my = base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mIdle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mIdle, 0u));
+            if (mode == 0u && my < n) {
+                idx = my;
+                const RayIn r = rays[idx];
+                O = mk3(r.O[0], r.O[1], r.O[2]); D = mk3(r.D[0], r.D[1], r.D[2]);
+                rD = mk3(1 / D.x, 1 / D.y, 1 / D.z);                      // Ray ctor, template/ray.h:15-24
+                h.t = 1e34f; h.u = 0; h.v = 0; h.objIdx = -1; h.triIdx = -1; traversed = 0; tested = 0;
+                cn.rays++;
+                hit_light_floor(sc, O, D, h);
+                if (sc.kind == 0) { Oo = O; Do = D; rDo = rD; cur = sc.rootRef; sp = 0; mode = 1u; }
+                else { tcur = sc.rootRef; tsp = 0; mode = 3u; }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(mode != 0u) == 0ull) break;       // nothing in flight, nothing left to draw
+        // ---------------- TLAS step (tlas_bvh.cpp:83-111): a leaf enters its BLAS, an interior node orders its children ----------------
+        if (mode == 3u) {
+            traversed++; cn.tlas++;
+            bool pop = false;
+            if ((tcur & kRefTlasLeaf) == kRefTlasLeaf) {
+                cn.visits++;
+                const uint32_t io = sc.instOff + (tcur & 0xffffu) * 128u;
+                const rec4 r0 = ldg(g, io), r1 = ldg(g, io + 16), r2 = ldg(g, io + 32), ids = ldg(g, io + 48);
+                to_object_space(r0, r1, r2, O, D, Oo, Do, rDo);
+                cur = asu(ids.z); sp = 0; mode = 1u;
+            } else {
+                const uint32_t o1 = sc.tlasOff + (tcur & 0x7fffu) * 32u, o2 = sc.tlasOff + ((tcur >> 15) & 0x7fffu) * 32u;
+                const rec4 alo = ldg(g, o1), ahi = ldg(g, o1 + 16), blo = ldg(g, o2), bhi = ldg(g, o2 + 16);
+                float d1 = box_exact(alo, ahi, O, rD, h.t), d2 = box_exact(blo, bhi, O, rD, h.t);
+                uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
+                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+                if (d1 == 1e30f) pop = true;
+                else { tcur = r1; if (d2 != 1e30f) { tstk[tsp * 64] = r2; tsp++; } }
+            }
+            if (pop) { if (tsp == 0) mode = 4u; else tcur = tstk[(--tsp) * 64]; }
+        }
+        // ---------------- BVH step (bvh.cpp:224-258): an interior node orders its children, a leaf starts its triangle list ----------------
+        bool back = false;                                                // this lane pops the BVH stack
+        if (mode == 1u) {
+            traversed++;
+            const uint32_t off = (cur & kRefOffsetMask) << 4;
+            if (cur & kRefInterior) {
+                cn.interior++;
+                const rec4 alo = ldg(g, off), ahi = ldg(g, off + 16), blo = ldg(g, off + 32), bhi = ldg(g, off + 48);
+                float d1 = box_exact(alo, ahi, Oo, rDo, h.t), d2 = box_exact(blo, bhi, Oo, rDo, h.t);
+                uint32_t r1 = asu(alo.w), r2 = asu(blo.w);
+                if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tr = r1; r1 = r2; r2 = tr; }
+                if (d1 == 1e30f) back = true;
+                else { cur = r1; if (d2 != 1e30f) { stk[sp * 64] = r2; sp++; } }
+            } else { cn.leaf++; leafAt = off; mode = 2u; }
+        }
+        // ---------------- one triangle of the leaf (bvh.cpp:232-243) ----------------
+        if (mode == 2u) {
+            const rec4 a = ldg(g, leafAt), b = ldg(g, leafAt + 16), c = ldg(g, leafAt + 32);
+            tested++; cn.tri++;
+            hit_tri(a, b, c, Oo, Do, h);
+            if (asu(c.w) <= 1u) { back = true; mode = 1u; } else leafAt += 48;
+        }
+        if (back) {
+            if (sp != 0) cur = stk[(--sp) * 64];
+            else if (sc.kind == 0) mode = 4u;                              // the BVH is done
+            else if (tsp == 0) mode = 4u;                                  // the BLAS is done: back to the TLAS loop, tlas_bvh.cpp:95
+            else { tcur = tstk[(--tsp) * 64]; mode = 3u; }
+        }
+        if (mode == 4u) {                                                  // finished: the result record, and the lane is free
+            if (h.objIdx >= 2) cn.meshhits++;
+            int triIdx = h.triIdx;
+            if (sc.kind != 0 && h.objIdx >= 2) triIdx -= (int)asu(ldg(g, sc.instOff + (uint32_t)(h.objIdx - 2) * 128u + 48u).x);   // - Instance::shadeBase
+            HitOut o; o.t = h.t; o.u = h.u; o.v = h.v; o.objIdx = h.objIdx; o.triIdx = triIdx; o.traversed = traversed; o.tested = tested;
+            hits[idx] = o;
+            mode = 0u;
+        }
     }
     uint32_t vals[8] = {cn.rays, cn.primary, cn.interior, cn.leaf, cn.tri, cn.tlas, cn.visits, cn.meshhits};
 #pragma unroll
@@ -873,11 +956,14 @@ extern "C" hipError_t crt_launch_accumulate(const void* slab, void* acc, uint32_
 }
 
 extern "C" hipError_t crt_launch_find_nearest(const crt::Scene* sc, const void* rays, void* hits, uint32_t n, crt::Counters* counters,
-                                              uint32_t ldsBytes, hipStream_t stream)
+                                              uint32_t ldsBytes, uint32_t* cursor, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    dim3 grid((n + 63u) / 64u), block(64);
-    hipLaunchKernelGGL(crt::find_nearest_kernel, grid, block, ldsBytes, stream, *sc, (const crt::RayIn*)rays, (crt::HitOut*)hits, n, counters);
+    if (!cursor) return hipErrorInvalidValue;
+    if (hipMemsetAsync(cursor, 0, 4, stream) != hipSuccess) return hipGetLastError();
+    const uint32_t need = (n + 63u) / 64u, fill = 256u * 16u;          // persistent wavefronts: enough to fill the device several times over, never more than the rays need
+    dim3 grid(need < fill ? need : fill), block(64);
+    hipLaunchKernelGGL(crt::find_nearest_kernel, grid, block, ldsBytes, stream, *sc, (const crt::RayIn*)rays, (crt::HitOut*)hits, n, counters, cursor);
     return hipGetLastError();
 }
 
