@@ -961,7 +961,8 @@ extern "C" hipError_t crt_launch_find_nearest(const crt::Scene* sc, const void* 
     if (n == 0) return hipSuccess;
     if (!cursor) return hipErrorInvalidValue;
     if (hipMemsetAsync(cursor, 0, 4, stream) != hipSuccess) return hipGetLastError();
-    const uint32_t need = (n + 63u) / 64u, fill = 256u * 16u;          // persistent wavefronts: enough to fill the device several times over, never more than the rays need
+    uint32_t perCu = ldsBytes ? (160u * 1024u) / ldsBytes : 16u; if (perCu > 16u) perCu = 16u; if (perCu < 4u) perCu = 4u;      // 4 wavefronts per SIMD, LDS stacks permitting (measured: 8 per SIMD is no faster for the grid and 17 % slower for the BVH)
+    const uint32_t need = (n + 63u) / 64u, fill = 256u * perCu;          // persistent wavefronts: the device full once, never more than the rays need
     dim3 grid(need < fill ? need : fill), block(64);
     hipLaunchKernelGGL(crt::find_nearest_kernel, grid, block, ldsBytes, stream, *sc, (const crt::RayIn*)rays, (crt::HitOut*)hits, n, counters, cursor);
     return hipGetLastError();
