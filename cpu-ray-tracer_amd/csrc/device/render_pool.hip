@@ -48,6 +48,12 @@ constexpr uint32_t kQueueMask = 127u;                            // queues are r
 #ifndef CRT_POOL_SHADE_MIN
 #define CRT_POOL_SHADE_MIN 64     // streams a shading pass waits for ...
 #endif
+#ifndef CRT_POOL_NODE_STEPS
+#define CRT_POOL_NODE_STEPS 2     // NODE steps per trip of the lanes that stay at interior nodes
+#endif
+#ifndef CRT_POOL_NODE2_MIN
+#define CRT_POOL_NODE2_MIN 16     // ... as long as at least this many lanes take the further step
+#endif
 #ifndef CRT_POOL_STARVE
 #define CRT_POOL_STARVE 40        // ... unless fewer than this many streams are walking or ready to walk
 #endif
@@ -215,6 +221,53 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
         trD = mk3(stf[F_RX * S + sid], stf[F_RY * S + sid], stf[F_RZ * S + sid]);
     };
 
+    // ---------------- NODE step (infra/bvh.cpp:244-257 / tlas_bvh.cpp:96-110) of the lanes in m, on their pre-loaded NodePair ----------------
+    uint64_t mNode2 = 0ull;
+    auto node_step = [&](uint64_t m) {
+        const bool allFinite = (m & ~mFinite) == 0ull;
+        if (lane_in(m)) {
+            if (COUNT) { if (KIND == 1 && (cur & kRef16TlasBit) != 0u) cn.tlas++; else cn.interior++; }
+            const uint32_t top = stk_top(spB);                               // speculative: lands during the slab arithmetic (the dummy entry when the stack is empty)
+            float d1, d2;
+            if (__builtin_expect(allFinite, 1)) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
+            else { d1 = box_exact(q0, q1, tO, trD, h.t); d2 = box_exact(q2, q3, tO, trD, h.t); }
+            const bool sw = d1 > d2;                                         // near child first (strict >: ties keep child 1)
+            const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
+            const uint32_t rn = sw ? asu(q3.w) : asu(q1.w), rf = sw ? asu(q1.w) : asu(q3.w);   // the children's ref16
+            stk_put(spB + 128u, rf);                                         // dead store unless `push`
+            const bool hitN = dn != 1e30f, push = hitN && df != 1e30f;
+            const bool pop = !hitN && spB != laneB;
+            cur = hitN ? rn : (pop ? top : kRefDone);
+            spB = spB + (push ? 128u : 0u) - (pop ? 128u : 0u);
+            if (COUNT && (cur & kRef16TagMask) == 0u && cur != kRefDone) cn.leaf++;
+        }
+    };
+    // the record of `cur` into q0..q3 for the lanes in m (the others keep theirs): record offset of a 16-bit reference = index * record size + section base (layout.h)
+    auto load_records = [&](uint64_t m) {
+        const uint32_t idx = cur & kRef16IndexMask;
+        const bool inter = (cur & kRef16Interior) != 0u;
+        uint32_t oa = idx * (inter ? 64u : 48u) + (inter ? 0u : sc.leafOff - 48u);             // NodePair | LeafTri (one multiply-add on selected operands: no divergent arms)
+        if (KIND == 1 && (cur & kRef16TlasBit) != 0u)
+            oa = (cur & kRef16Interior) ? sc.instOff + idx * 128u : sc.tlasPairOff + idx * 64u;   // TLAS leaf: Instance {invT rows, ids} | TLAS interior: its child pair
+        if (lane_in(m)) { q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, oa + 32u); q3 = ldg(geom, oa + 48u); }
+    };
+
+    // ---------------- TRI step of the lanes in m: one triangle of the current leaf (infra/bvh.cpp:203-222, 232-243), on the pre-loaded LeafTri ----------------
+    auto tri_step = [&](uint64_t m) {
+        CRT_DENS(3, 1); CRT_DENS(4, __popcll(m));
+        if (lane_in(m)) {
+            if (COUNT) cn.tri++;
+            const uint32_t top = stk_top(spB);
+            hit_tri(q0, q1, q2, tO, tD, h);
+            const bool more = asu(q2.w) > 1u;                                // the leaf's next LeafTri is the next index
+            const bool pop = !more && spB != laneB;
+            const uint32_t next = more ? cur + 1u : (pop ? top : kRefDone);
+            spB -= pop ? 128u : 0u;
+            if (COUNT && !more && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
+            cur = next;
+        }
+    };
+
 #ifdef CRT_POOL_STAMPS
     unsigned long long pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -232,7 +285,7 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
             asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
             CRT_DENS(22, __popcll(mRes));
             if (mNode) { CRT_DENS(1, 1); CRT_DENS(2, __popcll(mNode)); }
-            if (mTri) { CRT_DENS(3, 1); CRT_DENS(4, __popcll(mTri)); }
+
             if (KIND == 1 && mTlas) { CRT_DENS(23, 1); CRT_DENS(24, __popcll(mTlas)); }
             uint64_t mBack = 0ull;                                                 // lanes that popped the return marker: BLAS finished, back to the TLAS level
             if (KIND == 1 && mTlas != 0ull) {
@@ -249,43 +302,33 @@ __global__ __launch_bounds__(64, CRT_POOL_MIN_WAVES) void render_pool_kernel(con
                 }
                 mFinite = (mFinite & ~mTlas) | (mTlas & finite3_mask(trD));
             }
-            if (mNode != 0ull) {
-                // ---------------- NODE phase (infra/bvh.cpp:244-257) ------------------------------------------------------------------------
-                const bool allFinite = (mNode & ~mFinite) == 0ull;
-                if (lane_in(mNode)) {
-                    if (COUNT) { if (KIND == 1 && (cur & kRef16TlasBit) != 0u) cn.tlas++; else cn.interior++; }
-                    const uint32_t top = stk_top(spB);                               // speculative: lands during the slab arithmetic (the dummy entry when the stack is empty)
-                    float d1, d2;
-                    if (__builtin_expect(allFinite, 1)) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
-                    else { d1 = box_exact(q0, q1, tO, trD, h.t); d2 = box_exact(q2, q3, tO, trD, h.t); }
-                    const bool sw = d1 > d2;                                         // near child first (strict >: ties keep child 1)
-                    const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
-                    const uint32_t rn = sw ? asu(q3.w) : asu(q1.w), rf = sw ? asu(q1.w) : asu(q3.w);   // the children's ref16
-                    stk_put(spB + 128u, rf);                                         // dead store unless `push`
-                    const bool hitN = dn != 1e30f, push = hitN && df != 1e30f;
-                    const bool pop = !hitN && spB != laneB;
-                    cur = hitN ? rn : (pop ? top : kRefDone);
-                    spB = spB + (push ? 128u : 0u) - (pop ? 128u : 0u);
-                    if (COUNT && (cur & kRef16TagMask) == 0u && cur != kRefDone) cn.leaf++;
-                }
+            if (mNode != 0ull) node_step(mNode);
+#if CRT_POOL_NODE_STEPS > 1
+            // ---------------- further NODE steps in the same trip (while-while): the fixed part of a trip — swap out / in, queue bookkeeping, the pass decision — is
+            // paid once for several node steps of the lanes that stay at interior nodes.  The lanes that just stepped fetch their next record now (an interior pair, or
+            // the first triangle of a leaf, which then joins THIS trip's TRI phase); everyone else keeps the record the previous trip loaded.
+            uint64_t mLeafNow = 0ull;                                              // lanes that reached a leaf in an earlier step of this trip and have its first triangle loaded
+#pragma unroll
+            for (int rep = 1; rep < CRT_POOL_NODE_STEPS; rep++) {
+                const uint64_t mStepped = rep == 1 ? mNode : mNode2;
+                mNode2 = mStepped & (KIND == 0 ? __builtin_amdgcn_ballot_w64(cur > 0x7fffu) : __builtin_amdgcn_ballot_w64(cur - kRef16TlasBit < 0x8000u));
+                if ((uint32_t)__popcll(mNode2) < (uint32_t)CRT_POOL_NODE2_MIN) { mNode2 = 0ull; break; }
+                const uint64_t mLeaf = mStepped & __builtin_amdgcn_ballot_w64((cur & kRef16TagMask) == 0u) & ~__builtin_amdgcn_ballot_w64(cur == kRefDone);
+                load_records(mNode2 | mLeaf);
+                mLeafNow |= mLeaf;
+                CRT_DENS(28, 1); CRT_DENS(29, __popcll(mNode2));
+                node_step(mNode2);
             }
-            if (mTri != 0ull) {
-                if (lane_in(mTri)) {
-                    // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:203-222, 232-243) -------------------------------
-                    if (COUNT) cn.tri++;
-                    const uint32_t top = stk_top(spB);
-                    hit_tri(q0, q1, q2, tO, tD, h);
-                    const bool more = asu(q2.w) > 1u;                                // the leaf's next LeafTri is the next index
-                    const bool pop = !more && spB != laneB;
-                    const uint32_t next = more ? cur + 1u : (pop ? top : kRefDone);
-                    spB -= pop ? 128u : 0u;
-                    if (COUNT && !more && (next & kRef16TagMask) == 0u && next != kRefDone) cn.leaf++;
-                    cur = next;
-                }
-            }
+            const uint64_t mTriAll = mTri | mLeafNow;
+            const uint64_t mTriRan = mTriAll;
+#else
+            const uint64_t mTriAll = mTri;
+            const uint64_t mTriRan = mTriAll;
+#endif
+            if (mTriAll != 0ull) tri_step(mTriAll);
             if (KIND == 1) {
                 // a popped return marker: the BLAS is finished — back to the world-space ray, pop the TLAS entry below (rare: once per BLAS visit)
-                mBack = (mNode | mTri) & __builtin_amdgcn_ballot_w64(cur == kRef16Return);
+                mBack = (mNode | mTriRan) & __builtin_amdgcn_ballot_w64(cur == kRef16Return);
                 if (mBack != 0ull) {
                     if (lane_in(mBack)) {
                         world_ray();
