@@ -58,6 +58,9 @@ namespace crt {
 #define CRT_NODE_BATCH 1
 #endif
 
+#ifndef CRT_TILES_NODE_STEPS
+#define CRT_TILES_NODE_STEPS 2     // NODE steps per trip of the lanes that stay at interior nodes
+#endif
 #ifndef CRT_MIN_WAVES
 #define CRT_MIN_WAVES 5      // waves per SIMD the register budget must allow (<= 96 VGPRs)
 #endif
@@ -399,10 +402,52 @@ __global__ __launch_bounds__(64, CRT_MIN_WAVES) void render_tiles_kernel(const S
                 cur = next;
             }
         }
+        // ---------------- a second NODE step in the same trip (while-while, round 3): the lanes that just stepped and are still at an interior node fetch their next
+        // pair now and step again, so the trip's fixed part (state ballots, phase selection, the other phases' skeleton) is paid once per two node steps; a lane that
+        // just reached a leaf fetches its first triangle with them and joins THIS trip's TRI phase.  Same steps in the same order per lane.
+        bool triNow = isTri;
+#if CRT_TILES_NODE_STEPS > 1
+        if (runNode) {
+            const bool node2 = isNode && (KIND == 1 ? (((cur >> 31) ^ (cur >> 30)) & 1u) != 0u : (cur & 0xC0000000u) == kRefInterior);
+            const bool leaf2 = isNode && cur != kRefDone && (cur & 0xC0000000u) == 0u;
+            const uint64_t mNode2 = __builtin_amdgcn_ballot_w64(node2);
+            if (mNode2 != 0ull) {
+                if (node2 || leaf2) {
+                    uint32_t oa = (cur & kRefOffsetMask) << 4, ob = oa + 32u;                  // NodePair / LeafTri
+                    if (KIND == 1 && (cur & kRefTlasBit) != 0u) { oa = sc.tlasOff + (cur & 0x7fffu) * 32u; ob = sc.tlasOff + ((cur >> 15) & 0x7fffu) * 32u; }   // TLAS interior: the two child nodes
+                    q0 = ldg(geom, oa); q1 = ldg(geom, oa + 16u); q2 = ldg(geom, ob); q3 = ldg(geom, ob + 16u);
+                }
+                triNow = isTri || leaf2;
+                const bool allFinite2 = __builtin_amdgcn_ballot_w64(node2 && !rayFinite) == 0ull;
+                if (node2) {
+                    if (COUNT) { if (KIND == 1 && (cur & kRefTlasBit) != 0u) cn.tlas++; else cn.interior++; }
+                    uint32_t top = CRT_TOP();
+                    float d1, d2;
+                    if (allFinite2) { d1 = box_fast(q0, q1, tO, trD, h.t); d2 = box_fast(q2, q3, tO, trD, h.t); }
+                    else { d1 = box_exact(q0, q1, tO, trD, h.t); d2 = box_exact(q2, q3, tO, trD, h.t); }
+                    const bool sw = d1 > d2;
+                    const float dn = sw ? d2 : d1, df = sw ? d1 : d2;
+                    const uint32_t rn = sw ? asu(q2.w) : asu(q0.w), rf = sw ? asu(q0.w) : asu(q2.w);
+                    stk[sp * 64u] = rf;
+                    const bool hitN = dn != 1e30f, push = hitN && df != 1e30f;
+                    bool pop = !hitN && sp != 0u;
+                    uint32_t next = hitN ? rn : (pop ? top : kRefDone);
+                    sp = sp + (push ? 1u : 0u) - (pop ? 1u : 0u);
+                    if (KIND == 1 && next == kRefReturn) {
+                        tO = O; tD = D; trD = rD; rayFinite = finite3(rD);
+                        pop = sp != 0u; top = CRT_TOP();
+                        next = pop ? top : kRefDone; sp -= pop ? 1u : 0u;
+                    }
+                    if (COUNT && (next & 0xC0000000u) == 0u && next != kRefDone) cn.leaf++;
+                    cur = next;
+                }
+            }
+        }
+#endif
 #ifdef CRT_STAMPS
         CRT_STAMP(s4); stT[2] += s4 - s3;
 #endif
-        if (runTri && isTri) {
+        if ((runTri || triNow != isTri) && triNow) {
             // ---------------- TRI phase: one triangle of the current leaf (infra/bvh.cpp:203-222, 232-243) -----------
             if (COUNT) cn.tri++;
             uint32_t top = CRT_TOP();                                                // speculative, as in the NODE phase
