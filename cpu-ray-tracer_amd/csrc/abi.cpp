@@ -22,7 +22,6 @@ extern "C" uint32_t crt_render_resident_waves(int, int, uint32_t);
 extern "C" uint32_t crt_probe_paths();
 extern "C" hipError_t crt_launch_render(const crt::Scene*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, const uint32_t*, uint32_t, uint32_t*, uint32_t, unsigned long long*, hipStream_t);
 extern "C" size_t crt_pool_scratch_bytes_per_window(uint32_t);
-extern "C" hipError_t crt_launch_render_duo(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t*, unsigned long long*, hipStream_t);
 extern "C" hipError_t crt_launch_render_pool(const crt::Scene*, void*, void*, crt::Counters*, unsigned long long*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, uint32_t*, unsigned long long*, hipStream_t);
 extern "C" uint32_t crt_pool_streams(uint32_t frames);
 extern "C" uint32_t crt_narrow_max_lanes(void);
@@ -1416,11 +1415,9 @@ static hipError_t launch_render_kernels(crt_ctx* c, const Launch& L)
             st2 = c->streams[(size_t)(c->launchSeq++ % c->streams.size())];
             if (le == hipSuccess && st2 != st) le = hipStreamWaitEvent(st2, L.ev.a, 0);
         }
-        if (le == hipSuccess) {
-            const bool duo = L.nf >= 256u && hook("CRT_POOL_DUO");
-            le = (duo ? crt_launch_render_duo : crt_launch_render_pool)(&c->hScene, L.slab, scratch, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
+        if (le == hipSuccess)
+            le = crt_launch_render_pool(&c->hScene, L.slab, scratch, c->dCounters, c->dTileClocks, c->dTileOrder, c->tileFirst, c->tileStride, c->tileCount, (uint32_t)c->tilesX,
                                         L.sppFirst, L.nf, L.passes, c->cfg.collectStats, L.jobBlocks ? L.head : 0u, L.wantJobCost ? c->dJobCost : nullptr, L.jobClk, st2);
-        }
         if (L.jobBlocks && le == hipSuccess) le = join(st2);
     } else if (L.jobBlocks) {
         le = launch_table(c->dJobDesc, L.jobBlocks, L.jobBlocksWide, nullptr);

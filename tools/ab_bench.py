@@ -7,7 +7,7 @@ os.environ.setdefault("CRT_ENABLE_DEBUG_HOOKS", "1")      # the library reads it
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(REPO, "build", "variants")
 PKG = os.path.join(REPO, "cpu-ray-tracer_amd")
-SRC = ["csrc/device/kernels.hip", "csrc/device/render_pool.hip", "csrc/device/render_duo.hip", "csrc/device/render_narrow.hip", "csrc/device/render_prim.hip", "csrc/device/alt_accel.hip", "csrc/abi.cpp", "csrc/host/accel.cpp", "csrc/host/accel_alt.cpp", "csrc/host/loaders.cpp", "csrc/host/scene.cpp", "csrc/host/primitive_scene.cpp", "csrc/host/host_abi.cpp"]
+SRC = ["csrc/device/kernels.hip", "csrc/device/render_pool.hip", "csrc/device/render_narrow.hip", "csrc/device/render_prim.hip", "csrc/device/alt_accel.hip", "csrc/abi.cpp", "csrc/host/accel.cpp", "csrc/host/accel_alt.cpp", "csrc/host/loaders.cpp", "csrc/host/scene.cpp", "csrc/host/primitive_scene.cpp", "csrc/host/host_abi.cpp"]
 
 def fastbuild(specs):
     """variants that only differ in render_pool.hip: everything else is compiled once into build/obj/ and re-linked (seconds per variant)"""
@@ -17,7 +17,7 @@ def fastbuild(specs):
     for src in SRC:
         if src.endswith("render_pool.hip"): continue
         o = os.path.join(odir, os.path.basename(src) + ".o"); objs.append(o)
-        deps = [os.path.join(PKG, src)] + [os.path.join(PKG, "csrc/device", h) for h in ("dev_common.h", "layout.h", "pool_common.h")] + [os.path.join(REPO, "include", h) for h in ("crt_abi.h", "crt_host.h")]
+        deps = [os.path.join(PKG, src)] + [os.path.join(PKG, "csrc/device", h) for h in ("dev_common.h", "layout.h")] + [os.path.join(REPO, "include", h) for h in ("crt_abi.h", "crt_host.h")]
         if not os.path.exists(o) or any(os.path.getmtime(d) > os.path.getmtime(o) for d in deps):
             subprocess.check_call(base + ["-c", "-o", o, src], cwd=PKG)
     procs = []
