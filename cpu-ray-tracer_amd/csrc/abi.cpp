@@ -112,8 +112,8 @@ struct crt_ctx {
     int renderAccel = 0;                  // crt_set_render_accel: 0 = the scene's BVH / TLAS, CRT_ACCEL_KDTREE / CRT_ACCEL_GRID = Sample and Trace go through that structure
     crt::AltAccelDev alt{}; bool haveKd = false, haveGrid = false; std::vector<void*> altAllocs[2]; void* altTris = nullptr; uint32_t altTriCount = 0;   // KD-tree [0] / grid [1] buffers
     void* dQueryRays = nullptr; void* dQueryHits = nullptr; size_t queryCap = 0;      // crt_find_nearest staging (rays)
-    // Latency mode of single-window launches (render_tiles_kernel's block table), driven by measurement — see next_block_table.  Stage 0 = one wavefront per tile;
-    // stages 1 .. kLatStages = block tables, each built from the tile costs measured under the best stage so far; afterwards the fastest stage is used
+    // Latency mode of single-window launches (render_tiles_kernel's block table), driven by measurement — see next_block_table.  Stage 0 = the table solved from the cost probe's
+    // estimates (one wavefront per tile when there was no probe); stages 1 .. kLatStages = tables solved from the tile costs the stage before measured; afterwards the fastest stage is used
     // (HIP event durations of the launches themselves; identical pixels whatever the table).
     static constexpr int kLatStages = 4;       // (round 3: the stages are solved, not stepped, and agree within launch-to-launch scatter from stage 1 on; round 2's stepping tuner needed 6)
     double tuneMs[kLatStages + 1] = {}; int tuneCount[kLatStages + 1] = {};

@@ -24,7 +24,7 @@ def test_every_stage_of_the_latency_mode_renders_the_same_pixels(crt, orc, monke
     want = _oracle(orc, xml, kind, W, H, frames, passes)
     hs = crt.HostScene(scene_path(xml), kind, ASSETS)
     ctx = crt.Context(W, H); hs.upload(ctx)
-    for i in range(12):                                 # two one-wave launches, six table stages, two confirmation launches, then the fastest table
+    for i in range(12):                                 # the probed (or one-wave) launch, the table stages, two confirmation launches, then the fastest table
         ctx.clear(); ctx.render(1, frames, passes); ctx.sync()
         assert np.array_equal(ctx.accumulator(), want), "launch %d of the sequence differs" % i
         if i % 2: ctx.timing()                          # (a caller that reads the timing recycles the launches' event pairs: the tuner has looked at them before)
